@@ -1,0 +1,115 @@
+"""
+ctypes binding of libfastbox_hip.so (C ABI declared in include/fastbox_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails the
+binding raises.  The library is built in-tree by ``build_library()`` (hipcc,
+--offload-arch=gfx950) into ``fastbox_amd/lib/``.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfastbox_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+c_void_p, c_int, c_double, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+c_u64, c_i64 = ctypes.c_uint64, ctypes.c_int64
+P_double = ctypes.POINTER(ctypes.c_double)
+P_i32 = ctypes.POINTER(ctypes.c_int32)
+
+# name -> (restype, argtypes); must list every symbol of include/fastbox_hip.h
+SIGNATURES = {
+    "fb_version": (c_int, []),
+    "fb_last_error": (ctypes.c_char_p, []),
+    "fb_plan_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_double, c_double, c_double, c_int, c_int,
+                               P_double, P_double, P_double, P_double]),
+    "fb_plan_destroy": (c_int, [c_void_p]),
+    "fb_half_pitch": (c_int, [c_void_p]),
+    "fb_real_bytes": (c_i64, [c_void_p]),
+    "fb_half_bytes": (c_i64, [c_void_p]),
+    "fb_full_bytes": (c_i64, [c_void_p]),
+    "fb_fft_c2c": (c_int, [c_void_p, c_void_p, c_int, c_double, c_void_p]),
+    "fb_fft_r2c": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "fb_fft_c2r": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p]),
+    "fb_set_amplitude_shells": (c_int, [c_void_p, P_double, c_i64]),
+    "fb_set_amplitude_dense": (c_int, [c_void_p, c_void_p]),
+    "fb_colour_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fb_colour_philox": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p]),
+    "fb_set_bins": (c_int, [c_void_p, P_double, c_int, P_i32, P_i32, c_int]),
+    "fb_bin_power": (c_int, [c_void_p, c_void_p, c_int, P_double, P_double, P_double, c_void_p]),
+    "fb_apply_filter": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, P_double, c_void_p, c_void_p]),
+    "fb_velocity_k": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p]),
+    "fb_potential_k": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "fb_lognormal": (c_int, [c_void_p, c_void_p, c_void_p, P_double, c_void_p]),
+    "fb_redshift_space": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_u64,
+                                  c_void_p]),
+    "fb_sum_real": (c_int, [c_void_p, c_void_p, c_int, P_double, c_void_p]),
+    "fb_sumsq_half": (c_int, [c_void_p, c_void_p, P_double, c_void_p]),
+    "fb_expand_half": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fb_crop_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fb_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size_t]),
+    "fb_free": (c_int, [c_void_p]),
+    "fb_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fb_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fb_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fb_stream_sync": (c_int, [c_void_p]),
+    "fb_device_count": (c_int, [ctypes.POINTER(c_int)]),
+}
+
+FB_FILT_TABLE, FB_FILT_BEAM_HIGHPASS, FB_FILT_WEDGE, FB_FILT_TOPHAT = 0, 1, 2, 3
+
+
+class FastBoxError(RuntimeError):
+    """A libfastbox_hip call returned a non-zero status."""
+
+    def __init__(self, fn, code, msg):
+        RuntimeError.__init__(self, "%s failed (%d): %s" % (fn, code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def build_library(verbose=False, jobs=8):
+    """Compile every HIP source for gfx950 into fastbox_amd/lib/libfastbox_hip.so."""
+    cmd = ["make", "-C", CSRC, "-j%d" % jobs]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    if verbose or res.returncode:
+        print(res.stdout)
+    if res.returncode:
+        raise RuntimeError("building libfastbox_hip.so failed")
+    return LIB_PATH
+
+
+def load():
+    """dlopen the in-tree library and attach prototypes.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libfastbox_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` or `make -C fastbox_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(name, code):
+    if code != 0:
+        msg = load().fb_last_error()
+        raise FastBoxError(name, code, msg.decode("utf-8", "replace") if msg else "")
+
+
+def call(name, *args):
+    check(name, getattr(load(), name)(*args))
+
+
+def device_count():
+    n = c_int(0)
+    code = load().fb_device_count(ctypes.byref(n))
+    return n.value if code == 0 else 0

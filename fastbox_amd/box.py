@@ -1,0 +1,450 @@
+"""
+``CosmoBox`` -- drop-in for the density-field hot path of ``fastbox.box.CosmoBox``
+(philbull/FastBox, fastbox/box.py) with the arithmetic running as HIP kernels
+on an MI355X behind libfastbox_hip.so.
+
+Same constructor, method names, argument order, defaults and exceptions as the
+reference; fields are returned as ``DeviceArray`` objects that stay in HBM and
+turn into float64 / complex128 ndarrays when numpy touches them.  Additive,
+reference-preserving keyword arguments: ``precision`` ('f32' storage with fp64
+bin sums, or 'f64'), ``rng`` ('numpy' = the reference's legacy global stream,
+drawn on the host and uploaded -- same seed, same field; 'philox' = on-device
+counter-based RNG for throughput), ``seed``, ``device``, ``stream``.
+
+No CPU fallback exists: without the HIP library or a GPU every compute method
+raises.
+"""
+import numpy as np
+
+from . import cosmology as _builtin_cosmology
+from . import device as _dev
+from ._lib import FB_FILT_TABLE, FB_FILT_TOPHAT
+from .device import DeviceArray, Engine, FULL, HALF, REAL
+from .transfer import DeviceFilter
+
+try:                                        # the reference's provider, if present
+    import pyccl as _ccl
+except Exception:                           # not installed in this image
+    _ccl = _builtin_cosmology
+
+# Speed of light (m/s)
+C = 299792458.
+
+default_cosmo = dict(Omega_c=0.25, Omega_b=0.05, h=0.7, n_s=0.95, sigma8=0.8,
+                     transfer_function='eisenstein_hu')
+
+try:
+    from scipy.integrate import simpson as _simpson
+except Exception:                           # pragma: no cover
+    from scipy.integrate import simps as _simpson
+
+
+class CosmoBox(object):
+
+    def __init__(self, cosmo, box_scale=1e3, nsamp=32, redshift=0.,
+                 line_freq=1420.405752, realise_now=True,
+                 precision="f32", rng="numpy", seed=0, device=0, stream=None):
+        # box.py:61-64
+        if isinstance(cosmo, dict):
+            cosmo = _ccl.Cosmology(**cosmo)
+        if not isinstance(cosmo, _ccl.Cosmology):
+            raise TypeError("`cosmo` must be a CCL Cosmology object or dict.")
+        self.cosmo = cosmo
+        self.N = nsamp
+        self.redshift = redshift
+        self.scale_factor = 1. / (1. + redshift)
+        self.line_freq = line_freq
+
+        # grid including both end points, box.py:76-89
+        if isinstance(box_scale, tuple):
+            assert len(box_scale) == 3, "Must specify scale of x, y, z dimensions"
+            self.x, self.y, self.z = [np.linspace(-0.5 * s, 0.5 * s, nsamp) for s in box_scale]
+        else:
+            self.x = self.y = self.z = np.linspace(-0.5 * box_scale, 0.5 * box_scale, nsamp)
+        self.Lx = self.x[-1] - self.x[0]
+        self.Ly = self.y[-1] - self.y[0]
+        self.Lz = self.z[-1] - self.z[0]
+        self.boxfactor = (self.N ** 6.) / (self.Lx * self.Ly * self.Lz)      # box.py:94
+        self.kmin = 2. * np.pi / np.max([self.Lx, self.Ly, self.Lz])          # box.py:100
+        self.kmax = 2. * np.pi * np.sqrt(3.) * self.N / np.min([self.Lx, self.Ly, self.Lz])
+
+        if rng not in ("numpy", "philox"):
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        self.rng, self.seed, self._realisation = rng, int(seed), 0
+        self._cubic = (self.Lx == self.Ly == self.Lz)
+        self._grids = None
+        self._amp_key = None
+        self._delta_k = None
+        self.set_fft_sample_spacing()
+        self.engine = Engine(self.N, (self.Lx, self.Ly, self.Lz), self._axis2, self._ksc, self._kpar, self.z,
+                             precision=precision, device=device, stream=stream)
+
+        if realise_now:                                                       # box.py:104-107
+            self.realise_density()
+            self.realise_velocity()
+            self.realise_potential()
+
+    # ------------------------------------------------------------------ k grids
+    def set_fft_sample_spacing(self):
+        """1-D tables behind |k|, k_perp, k_par (box.py:119-127, 254-256, 374-375).  The
+        (N,N,N) arrays Kx, Ky, Kz, k of the reference are never built on the device; the
+        attributes of the same name materialise them on the host on first access."""
+        N = self.N
+        m = (N * np.fft.fftfreq(N, 1.)).astype("i").astype(np.float64)
+        self._modes = m
+        L = (self.Lx, self.Ly, self.Lz)
+        self._axis2 = np.concatenate([(m / l) ** 2. for l in L])
+        self._ksc = np.concatenate([m * (2. * np.pi / l) for l in L])
+        self._kpar = 2. * np.pi * m / self.Lz
+        self._grids = None
+
+    def _host_grids(self):
+        if self._grids is None:
+            N, m = self.N, self._modes
+            ones = np.ones((N, N, N))
+            Kx, Ky, Kz = m[:, None, None] * ones, m[None, :, None] * ones, m[None, None, :] * ones
+            k = 2. * np.pi * np.sqrt((Kx / self.Lx) ** 2. + (Ky / self.Ly) ** 2. + (Kz / self.Lz) ** 2.)
+            self._grids = (Kx, Ky, Kz, k)
+        return self._grids
+
+    Kx = property(lambda self: self._host_grids()[0])
+    Ky = property(lambda self: self._host_grids()[1])
+    Kz = property(lambda self: self._host_grids()[2])
+    k = property(lambda self: self._host_grids()[3])
+
+    # --------------------------------------------------------------- conversions
+    def _as_real(self, a):
+        if isinstance(a, DeviceArray):
+            if a.kind != REAL:
+                raise TypeError("expected a real-space field")
+            return a
+        a = np.asarray(a)
+        if np.iscomplexobj(a):
+            a = a.real
+        return self.engine.upload(a, REAL)
+
+    def _as_spectrum(self, a):
+        """DeviceArray half/full, or a host complex (N,N,N) array uploaded as 'full'."""
+        if isinstance(a, DeviceArray):
+            if a.kind == REAL:
+                raise TypeError("expected a Fourier-space field")
+            return a
+        return self.engine.upload(np.asarray(a), FULL)
+
+    @property
+    def delta_k(self):
+        """fftn(delta_x) (box.py:193), computed on first use after a realisation."""
+        if self._delta_k is None:
+            if getattr(self, "delta_x", None) is None:
+                raise AttributeError("'CosmoBox' object has no attribute 'delta_k'")
+            self._delta_k = self.engine.fft_r2c(self.delta_x)
+        return self._delta_k
+
+    @delta_k.setter
+    def delta_k(self, value):
+        self._delta_k = None if value is None else self._as_spectrum(value)
+
+    def to_real(self, field_k):
+        """Real part of ifftn(field_k) as a device field (what callers of the reference
+        write as ``np.fft.ifftn(box.velocity_k[2]).real``)."""
+        f = self._as_spectrum(field_k)
+        if f.kind == HALF:
+            return self.engine.fft_c2r(f)
+        full = self.engine.fft_c2c(f, +1, 1.0 / self.N ** 3)
+        return self.engine.upload(full.host().real, REAL)
+
+    # --------------------------------------------------------- Gaussian realisation
+    def _power(self, k, scale_factor, linear):
+        fn = _ccl.linear_matter_power if linear else _ccl.nonlin_matter_power
+        return fn(self.cosmo, k=k, a=scale_factor)
+
+    def _set_amplitude(self, scale_factor, linear):
+        """sqrt(nan_to_num(P(k)) * boxfactor), box.py:161-171, on unique |k| shells for a
+        cubic box, per stored mode otherwise."""
+        key = (float(scale_factor), bool(linear))
+        if key == self._amp_key:
+            return
+        N = self.N
+        with np.errstate(all="ignore"):
+            if self._cubic:
+                n2 = np.arange(3 * (N // 2) ** 2 + 1, dtype=np.float64)
+                k = 2. * np.pi * np.sqrt(n2) / self.Lx
+                pk = np.nan_to_num(np.asarray(self._power(k, scale_factor, linear), dtype=np.float64))
+                self.engine.set_amplitude_shells(np.sqrt(pk * self.boxfactor))
+            else:
+                nz = N // 2 + 1
+                a = self._axis2
+                s = (a[:N, None, None] + a[N:2 * N][None, :, None]) + a[2 * N:][None, None, :nz]
+                k = 2. * np.pi * np.sqrt(s)
+                pk = np.nan_to_num(np.asarray(self._power(k.flatten(), scale_factor, linear), dtype=np.float64))
+                self.engine.set_amplitude_dense(np.sqrt(pk.reshape(k.shape) * self.boxfactor))
+        self._amp_key = key
+
+    def realise_density(self, linear=False, redshift=None, inplace=True):
+        """Gaussian random field with the matter power spectrum (box.py:130-194).
+
+        rng='numpy': ``re`` then ``im`` are drawn from the legacy global numpy stream
+        exactly as the reference does, so ``np.random.seed(s)`` gives the same field.
+        Conscious fix: with ``inplace=False`` the reference transforms a *stale*
+        ``self.delta_k`` (box.py:187); here the new field is returned.
+        """
+        if redshift is None:
+            redshift = self.redshift
+        scale_factor = 1. / (1. + redshift)
+        self._set_amplitude(scale_factor, linear)
+        eng = self.engine
+        N = self.N
+        if self.rng == "numpy":
+            re = eng.upload(np.random.normal(0.0, 1.0, (N, N, N)), REAL)
+            im = eng.upload(np.random.normal(0.0, 1.0, (N, N, N)), REAL)
+            half = eng.colour_noise(re, im)
+            del re, im
+        else:
+            half = eng.colour_philox(self.seed, self._realisation)
+            self._realisation += 1
+        delta_x = eng.fft_c2r(half, destroy=True)
+        if inplace:
+            if redshift != self.redshift:
+                print("Warning: Storing density field into self.delta_x with a "
+                      "different redshift than self.redshift.")
+            self.delta_x = delta_x
+            self._delta_k = None          # = fftn(delta_x), materialised on demand
+        return delta_x
+
+    # ----------------------------------------------------------- velocity / potential
+    def _field_k(self, delta_x, delta_k):
+        if delta_x is not None and delta_k is not None:
+            raise ValueError("delta_x and delta_k specified; can only specify one")
+        if delta_x is not None:
+            return self.engine.fft_r2c(self._as_real(delta_x))
+        if delta_k is None:
+            return self.delta_k
+        return self._as_spectrum(delta_k)
+
+    def realise_velocity(self, delta_x=None, delta_k=None, redshift=None, inplace=True):
+        """v(k) = i [f H a] delta_k k_vec / k^2 per component (box.py:197-290)."""
+        if redshift is None:
+            redshift = self.redshift
+        scale_factor = 1. / (1. + redshift)
+        dk = self._field_k(delta_x, delta_k)
+        if self.N % 2 != 0:
+            raise UnboundLocalError("local variable 'mx' referenced before assignment")
+        fac = 100. * self.cosmo['h'] * _ccl.h_over_h0(self.cosmo, a=scale_factor) \
+            * _ccl.growth_rate(self.cosmo, a=scale_factor) * scale_factor
+        velocity_k = tuple(self.engine.velocity_k(dk, c, fac) for c in range(3))
+        if inplace:
+            self.velocity_k = velocity_k
+        return velocity_k
+
+    def realise_potential(self, delta_x=None, delta_k=None, redshift=None, inplace=True):
+        """delta_k / k^2 with the monopole zeroed; like the reference the physical
+        prefactor is not applied (box.py:344-348)."""
+        dk = self._field_k(delta_x, delta_k)
+        phi_k = self.engine.potential_k(dk)
+        if inplace:
+            self.phi_k = phi_k
+        return phi_k
+
+    # ------------------------------------------------------------------- filters
+    def _filter_table(self, transfer_fn, layout_kind):
+        """Evaluate an arbitrary callable on the host grid (as box.py:374-378 does)."""
+        N = self.N
+        m = self._modes
+        ones = np.ones((N, N, N))
+        k_perp = 2. * np.pi * np.sqrt(((m / self.Lx) ** 2.)[:, None, None] + ((m / self.Ly) ** 2.)[None, :, None]) * ones
+        k_par = (2. * np.pi * m / self.Lz)[None, None, :] * ones
+        with np.errstate(all="ignore"):
+            t = np.asarray(transfer_fn(k_perp, k_par))
+        if np.iscomplexobj(t):
+            raise TypeError("complex-valued transfer functions are not supported on the device")
+        t = np.broadcast_to(t, (N, N, N)).astype(self.engine.rdtype)
+        if layout_kind == HALF:
+            padded = np.zeros((N, N, self.engine.pitch), dtype=self.engine.rdtype)
+            padded[:, :, :N // 2 + 1] = t[:, :, :N // 2 + 1]
+            t = padded
+        return self.engine.upload_raw(t)
+
+    def apply_transfer_fn(self, field_k, transfer_fn):
+        """ifftn(nan_to_num(field_k * T(k_perp, k_par))) (box.py:356-381); the result is
+        complex like the reference's.  A Hermitian (device half-spectrum) field with a
+        ``DeviceFilter`` that is even in k_par takes the real-field fast path."""
+        eng = self.engine
+        f = self._as_spectrum(field_k)
+        if isinstance(transfer_fn, DeviceFilter):
+            if f.kind == HALF and not transfer_fn.even_in_kpar:
+                f = eng.expand_half(f)
+            dk = eng.apply_filter(f, transfer_fn.kind, transfer_fn.params)
+        else:
+            if f.kind == HALF:
+                f = eng.expand_half(f)     # an arbitrary callable need not be even in k_par
+            table = self._filter_table(transfer_fn, FULL)
+            dk = eng.apply_filter(f, FB_FILT_TABLE, table=table)
+        if dk.kind == HALF:
+            return eng.fft_c2r(dk, destroy=True, as_complex=True)
+        return eng.fft_c2c(dk, +1, 1.0 / self.N ** 3, inplace=True)
+
+    apply_filter = apply_transfer_fn
+
+    def window(self, k, R):
+        """Top-hat window squared (box.py:595-613)."""
+        return self.window1(k, R) ** 2.
+
+    def window1(self, k, R):
+        """Top-hat window (box.py:615-633)."""
+        x = k * R
+        return (3. / x ** 3.) * (np.sin(x) - x * np.cos(x))
+
+    def smooth_field(self, field_k, R):
+        """Top-hat smoothing with radius R Mpc/h (box.py:635-655)."""
+        eng = self.engine
+        f = self._as_spectrum(field_k)
+        dk = eng.apply_filter(f, FB_FILT_TOPHAT, (R / self.cosmo['h'], 0, 0, 0))
+        if dk.kind == HALF:
+            return eng.fft_c2r(dk, destroy=True, as_complex=True)
+        return eng.fft_c2c(dk, +1, 1.0 / self.N ** 3, inplace=True)
+
+    # ---------------------------------------------------------------- redshift space
+    def redshift_space_density(self, delta_x=None, velocity_z=None, sigma_nl=0., method='linear'):
+        """Line-of-sight remap to redshift space (box.py:384-438)."""
+        if method != 'linear':
+            raise NotImplementedError("only method='linear' runs on the device")
+        Hz = 100. * self.cosmo['h'] * _ccl.h_over_h0(self.cosmo, self.scale_factor)
+        d = self._as_real(delta_x)
+        v = self._as_real(velocity_z)
+        noise = None
+        if sigma_nl > 0. and self.rng == "numpy":
+            # the reference draws N normals per line of sight in (i, j) order (box.py:416-418)
+            noise = self.engine.upload(np.random.normal(0., 1., (self.N, self.N, self.N)), REAL)
+        seed = self.seed + 0x9E3779B97F4A7C15 * (self._realisation + 1)
+        return self.engine.redshift_space(d, v, Hz, sigma_nl, noise, seed)
+
+    # ------------------------------------------------------------------- log-normal
+    def lognormal(self, delta_x):
+        """exp(delta)/<exp(delta)> - 1 (box.py:441-460)."""
+        out, _ = self.engine.lognormal(self._as_real(delta_x))
+        return out
+
+    # ----------------------------------------------------------------- power spectrum
+    def _shell_thresholds(self, bins):
+        """Bin as a step function of the integer shell n^2 (cubic boxes).  A shell whose
+        |k| is within rounding of an edge is left to the exact on-device expression."""
+        N = self.N
+        n2 = np.arange(3 * (N // 2) ** 2 + 1, dtype=np.float64)
+        k = 2. * np.pi * np.sqrt(n2) / self.Lx
+        eps = 64 * np.finfo(np.float64).eps
+        lo = np.digitize(k * (1. - eps), bins)
+        hi = np.digitize(k * (1. + eps), bins)
+        amb = np.nonzero(lo != hi)[0]
+        if amb.size > 8:
+            return None, ()
+        thr = np.searchsorted(hi, np.arange(1, bins.size + 1), side="left")
+        return thr.astype(np.int32), tuple(int(a) for a in amb)
+
+    def binned_power_spectrum(self, delta_x=None, delta_k=None, nbins=20, kbins=None):
+        """Shell-averaged power spectrum of the realisation (box.py:696-768): bin centres,
+        mean of |delta_k|^2/boxfactor and std/sqrt(n) per bin; bin 0 is dropped and empty
+        bins are NaN, as in the reference."""
+        if delta_x is not None and delta_k is not None:
+            raise ValueError("delta_x and delta_k specified; can only specify one")
+        if delta_x is not None:
+            spec = self.engine.fft_r2c(self._as_real(delta_x))
+        elif delta_k is None:
+            spec = self.delta_k
+        else:
+            spec = self._as_spectrum(delta_k)
+        if kbins is not None:
+            bins = np.asarray(kbins, dtype=np.float64)
+        else:
+            bins = np.logspace(np.log10(self.kmin), np.log10(self.kmax), nbins)   # box.py:749
+        _bins = [0.0] + list(bins)
+        cent = [0.5 * (_bins[j + 1] + _bins[j]) for j in range(bins.size)]
+
+        thr, amb = (None, ())
+        if self._cubic and np.all(np.diff(bins) >= 0):
+            thr, amb = self._shell_thresholds(bins)
+        self.engine.set_bins(bins, thr, amb)
+        cnt, s1, s2 = self.engine.bin_power(spec)
+        with np.errstate(all="ignore"):
+            vals = s1 / (cnt * self.boxfactor)
+            var = s2 / (cnt * self.boxfactor ** 2) - vals ** 2
+            stddev = np.sqrt(np.maximum(var, 0.)) / np.sqrt(cnt)
+        return np.array(cent[1:]), np.array(vals[1:]), np.array(stddev[1:])
+
+    def sigmaR(self, R):
+        """RMS of the field smoothed with a top-hat of R Mpc/h, from the binned power
+        spectrum (box.py:657-683; scipy's simps is spelled simpson since 1.14)."""
+        k, pk, stddev = self.binned_power_spectrum()
+        good = ~np.isnan(pk)
+        pk, k = pk[good], k[good]
+        y = k ** 2. * pk * self.window(k, R / self.cosmo['h'])
+        I = _simpson(y, x=k)
+        return np.sqrt(I / (2. * np.pi ** 2.))
+
+    def sigma8(self):
+        return self.sigmaR(8.0)
+
+    def theoretical_power_spectrum(self):
+        """box.py:770-782."""
+        k = np.logspace(-3.5, 1., int(1e3))
+        pk = _ccl.nonlin_matter_power(self.cosmo, k=k, a=self.scale_factor)
+        return k, pk
+
+    # ----------------------------------------------------------------- coordinates
+    def freq_array(self, redshift=None):
+        """Channel frequencies in MHz, decreasing along z (box.py:789-828)."""
+        if redshift is None:
+            redshift = self.redshift
+        a = 1. / (1. + redshift)
+        dx = self.Lz / self.N
+        Hz = 100. * self.cosmo['h'] * _ccl.h_over_h0(self.cosmo, a)
+        df = dx * self.line_freq * (a ** 2. * Hz) / (C / 1e3)
+        freqs = a * self.line_freq + df * (np.arange(self.N) - 0.5 * (self.N - 1.))
+        return freqs[::-1]
+
+    def pixel_array(self, redshift=None):
+        """Angular pixel coordinates in degrees (box.py:831-864)."""
+        if redshift is None:
+            redshift = self.redshift
+        r = _ccl.comoving_angular_distance(self.cosmo, 1. / (1. + redshift))
+        ang_x = (180. / np.pi) * ((self.x[1] - self.x[0]) / r)
+        ang_y = (180. / np.pi) * ((self.y[1] - self.y[0]) / r)
+        grid = np.arange(self.N) - 0.5 * (self.N - 1.)
+        return ang_x * grid, ang_y * grid
+
+    # ------------------------------------------------------------------ self tests
+    def test_parseval(self):
+        """sum(delta_x^2) N^3 against sum |delta_k|^2 (box.py:931-948), both reduced on
+        the device in fp64."""
+        s1 = self.engine.sum_real(self.delta_x, squared=True) * self.N ** 3.
+        s2 = self.engine.sumsq_half(self.delta_k) if self.delta_k.kind == HALF \
+            else float(np.sum(np.abs(self.delta_k.host()) ** 2))
+        print("Parseval test:", s1 / s2, "(should be 1.0)")
+        return s1, s2
+
+    def test_sampling_error(self):
+        """sigma8 of the realisation against theory (box.py:871-928)."""
+        h = self.cosmo['h']
+        s8_real = self.sigma8()
+        _k = np.linspace(self.kmin, self.kmax, int(5e3))
+        _pk = _ccl.nonlin_matter_power(self.cosmo, k=_k, a=self.scale_factor)
+        _y = np.nan_to_num(_k ** 2. * _pk * self.window(_k, 8.0 / h))
+        s8_th_win = np.sqrt(_simpson(_y, x=_k) / (2. * np.pi ** 2.))
+        _k2 = np.logspace(-5, 2, int(5e4))
+        _pk2 = _ccl.nonlin_matter_power(self.cosmo, k=_k2, a=self.scale_factor)
+        _y2 = np.nan_to_num(_k2 ** 2. * _pk2 * self.window(_k2, 8.0 / h))
+        s8_th_full = np.sqrt(_simpson(_y2, x=_k2) / (2. * np.pi ** 2.))
+        s8_realspace = np.std(np.asarray(self.smooth_field(self.delta_k, 8.0)))
+        s20_realspace = np.std(np.asarray(self.smooth_field(self.delta_k, 20.0)))
+        s20_real = self.sigmaR(20.)
+        print("")
+        print("sigma8 (real.): \t", s8_real)
+        print("sigma8 (th.win.):\t", s8_th_win)
+        print("sigma8 (th.full):\t", s8_th_full)
+        print("sigma8 (realsp.):\t", s8_realspace)
+        print("ratio =", 1. / (s8_real / s8_realspace))
+        print("")
+        print("sigma20 (real.): \t", s20_real)
+        print("sigma20 (realsp.):\t", s20_realspace)
+        print("ratio =", 1. / (s20_real / s20_realspace))
+        print("var(delta) =", np.sqrt(self.engine.sum_real(self.delta_x, True) / self.N ** 3
+                                      - (self.engine.sum_real(self.delta_x) / self.N ** 3) ** 2))

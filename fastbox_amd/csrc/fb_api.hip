@@ -1,0 +1,261 @@
+// extern "C" surface of libfastbox_hip.so (see include/fastbox_hip.h).
+#include "../../include/fastbox_hip.h"
+#include "fb_plan.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static thread_local std::string g_last_error;
+
+void fb_set_error(const std::string& msg) { g_last_error = msg; }
+
+int fb_hip_check(hipError_t e, const char* what) {
+    if (e == hipSuccess) return FB_OK;
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP;
+}
+
+#define FB_REQUIRE(cond, msg) do { if (!(cond)) { fb_set_error(msg); return FB_ERR_INVALID; } } while (0)
+#define FB_DISPATCH(p, call32, call64) ((p)->prec == 4 ? (call32) : (call64))
+
+namespace {
+template <typename T> int upload(T** dst, const T* src, size_t n) {
+    FB_HIP(hipMalloc(reinterpret_cast<void**>(dst), n * sizeof(T)));
+    FB_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return FB_OK;
+}
+template <typename T> int make_twiddles(void** out, int N) {
+    std::vector<T> h((size_t)2 * N);
+    for (int j = 0; j < N; ++j) {
+        const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)N;
+        h[2 * (size_t)j] = (T)cosl(a);
+        h[2 * (size_t)j + 1] = (T)sinl(a);
+    }
+    FB_HIP(hipMalloc(out, h.size() * sizeof(T)));
+    FB_HIP(hipMemcpy(*out, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return FB_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int fb_version(void) { return 100; }
+const char* fb_last_error(void) { return g_last_error.c_str(); }
+
+int fb_device_count(int* count) {
+    FB_REQUIRE(count, "null pointer");
+    FB_HIP(hipGetDeviceCount(count));
+    return FB_OK;
+}
+
+int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int precision, int device,
+                   const double* axis2, const double* ksc, const double* kpar, const double* zgrid) {
+    FB_REQUIRE(plan && axis2 && ksc && kpar && zgrid, "null pointer");
+    FB_REQUIRE(precision == 4 || precision == 8, "precision must be 4 or 8");
+    FB_REQUIRE(Lx > 0 && Ly > 0 && Lz > 0, "box sides must be positive");
+    if (N < 16 || N > 2048 || (N & (N - 1))) {
+        fb_set_error("unsupported grid size: nsamp must be a power of two in 16..2048");
+        return FB_ERR_UNSUPPORTED;
+    }
+    FB_HIP(hipSetDevice(device));
+    fb_plan* p = new fb_plan();
+    p->N = N; p->prec = precision; p->device = device;
+    p->L[0] = Lx; p->L[1] = Ly; p->L[2] = Lz;
+    p->cubic = (Lx == Ly && Ly == Lz);
+    p->NZV = N / 2 + 1;
+    p->NZP = (p->NZV + 15) & ~15;
+    int r = precision == 4 ? make_twiddles<float>(&p->tw, N) : make_twiddles<double>(&p->tw, N);
+    if (!r) r = upload(&p->axis2, axis2, (size_t)3 * N);
+    if (!r) r = upload(&p->ksc, ksc, (size_t)3 * N);
+    if (!r) r = upload(&p->kpar, kpar, (size_t)N);
+    if (!r) r = upload(&p->zgrid, zgrid, (size_t)N);
+    p->prow = 1024;
+    if (!r) r = fb_hip_check(hipMalloc((void**)&p->partials, (size_t)p->prow * 2 * FB_MAX_BINS * sizeof(double)), "hipMalloc");
+    if (!r) r = fb_hip_check(hipMalloc((void**)&p->scratch, FB_SCRATCH * sizeof(double)), "hipMalloc");
+    if (!r) r = fb_hip_check(hipMalloc((void**)&p->counts, FB_MAX_BINS * sizeof(unsigned long long)), "hipMalloc");
+    if (!r) r = fb_hip_check(hipMalloc((void**)&p->bins, FB_MAX_BINS * sizeof(double)), "hipMalloc");
+    if (!r) r = fb_hip_check(hipMalloc((void**)&p->thr, FB_MAX_BINS * sizeof(int)), "hipMalloc");
+    if (r) { fb_plan_destroy(p); return r; }
+    p->nbins = 0;
+    *plan = p;
+    return FB_OK;
+}
+
+int fb_plan_destroy(fb_plan* p) {
+    if (!p) return FB_OK;
+    void* ptrs[] = {p->tw, p->axis2, p->ksc, p->kpar, p->zgrid, p->amp_shell, p->bins, p->thr, p->counts,
+                    p->partials, p->scratch};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    delete p;
+    return FB_OK;
+}
+
+int fb_half_pitch(const fb_plan* p) { return p ? p->NZP : 0; }
+int64_t fb_real_bytes(const fb_plan* p) { return p ? (int64_t)p->N * p->N * p->N * p->prec : 0; }
+int64_t fb_half_bytes(const fb_plan* p) { return p ? (int64_t)p->N * p->N * p->NZP * 2 * p->prec : 0; }
+int64_t fb_full_bytes(const fb_plan* p) { return p ? (int64_t)p->N * p->N * p->N * 2 * p->prec : 0; }
+
+int fb_fft_c2c(fb_plan* p, void* d, int direction, double scale, void* stream) {
+    FB_REQUIRE(p && d, "null pointer");
+    FB_REQUIRE(direction == 1 || direction == -1, "direction must be +1 or -1");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_fft_c2c_f32(p, d, direction, scale, s), fbi_fft_c2c_f64(p, d, direction, scale, s));
+}
+int fb_fft_r2c(fb_plan* p, const void* in, void* out, int pre_exp, void* stream) {
+    FB_REQUIRE(p && in && out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_fft_r2c_f32(p, in, out, pre_exp, s), fbi_fft_r2c_f64(p, in, out, pre_exp, s));
+}
+int fb_fft_c2r(fb_plan* p, void* half, void* out, double scale, void* stream) {
+    FB_REQUIRE(p && half && out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_fft_c2r_f32(p, half, out, scale, s), fbi_fft_c2r_f64(p, half, out, scale, s));
+}
+
+int fb_set_amplitude_shells(fb_plan* p, const double* amp, int64_t nshell) {
+    FB_REQUIRE(p && amp, "null pointer");
+    FB_REQUIRE(p->cubic, "shell amplitudes need a cubic box (use fb_set_amplitude_dense)");
+    const int64_t need = 3LL * (p->N / 2) * (p->N / 2) + 1;
+    FB_REQUIRE(nshell == need, "nshell must be 3 (N/2)^2 + 1");
+    p->amp_dense = nullptr;
+    return FB_DISPATCH(p, fbi_set_amp_shells_f32(p, amp, nshell), fbi_set_amp_shells_f64(p, amp, nshell));
+}
+int fb_set_amplitude_dense(fb_plan* p, const void* amp_dev) {
+    FB_REQUIRE(p && amp_dev, "null pointer");
+    p->amp_dense = amp_dev;
+    return FB_OK;
+}
+int fb_colour_noise(fb_plan* p, const void* re, const void* im, void* out, void* stream) {
+    FB_REQUIRE(p && re && im && out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_colour_noise_f32(p, re, im, out, s), fbi_colour_noise_f64(p, re, im, out, s));
+}
+int fb_colour_philox(fb_plan* p, uint64_t seed, uint64_t realisation, void* out, void* stream) {
+    FB_REQUIRE(p && out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_colour_philox_f32(p, seed, realisation, out, s),
+                       fbi_colour_philox_f64(p, seed, realisation, out, s));
+}
+
+int fb_set_bins(fb_plan* p, const double* edges, int nbins, const int32_t* thr, const int32_t* amb, int namb) {
+    FB_REQUIRE(p && edges, "null pointer");
+    FB_REQUIRE(nbins >= 1 && nbins <= FB_MAX_BINS, "nbins must be in 1..256");
+    FB_REQUIRE(namb >= 0 && namb <= 8, "at most 8 ambiguous shells");
+    for (int q = 1; q < nbins; ++q) FB_REQUIRE(edges[q] >= edges[q - 1], "bin edges must be ascending");
+    FB_REQUIRE(!thr || p->cubic, "shell thresholds need a cubic box");
+    FB_HIP(hipMemcpy(p->bins, edges, (size_t)nbins * sizeof(double), hipMemcpyHostToDevice));
+    p->nbins = nbins;
+    static_assert(sizeof(int) == sizeof(int32_t), "int");
+    p->namb = 0;
+    p->use_thr = thr ? 1 : 0;
+    if (thr) {
+        FB_HIP(hipMemcpy(p->thr, thr, (size_t)nbins * sizeof(int), hipMemcpyHostToDevice));
+        p->namb = namb;
+        for (int q = 0; q < namb; ++q) p->amb[q] = amb[q];
+    }
+    return fbi_bin_count(p, 0);
+}
+
+int fb_bin_power(fb_plan* p, const void* spec, int layout, double* count, double* sum, double* sumsq, void* stream) {
+    FB_REQUIRE(p && spec && count && sum && sumsq, "null pointer");
+    FB_REQUIRE(layout == 0 || layout == 1, "layout must be 0 (full) or 1 (half)");
+    hipStream_t s = (hipStream_t)stream;
+    int r = FB_DISPATCH(p, fbi_bin_power_f32(p, spec, layout, p->scratch, s), fbi_bin_power_f64(p, spec, layout, p->scratch, s));
+    if (r) return r;
+    std::vector<double> h((size_t)2 * p->nbins);
+    FB_HIP(hipMemcpyAsync(h.data(), p->scratch, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    FB_HIP(hipStreamSynchronize(s));
+    for (int q = 0; q < p->nbins; ++q) {
+        count[q] = p->counts_host[q];
+        sum[q] = h[(size_t)2 * q];
+        sumsq[q] = h[(size_t)2 * q + 1];
+    }
+    return FB_OK;
+}
+
+int fb_apply_filter(fb_plan* p, const void* in, void* out, int layout, int kind, const double* params,
+                    const void* table_dev, void* stream) {
+    FB_REQUIRE(p && in && out, "null pointer");
+    FB_REQUIRE(layout == 0 || layout == 1, "layout must be 0 (full) or 1 (half)");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_apply_filter_f32(p, in, out, layout, kind, params, table_dev, s),
+                       fbi_apply_filter_f64(p, in, out, layout, kind, params, table_dev, s));
+}
+int fb_velocity_k(fb_plan* p, const void* dk, void* out, int layout, int component, double fac, void* stream) {
+    FB_REQUIRE(p && dk && out, "null pointer");
+    FB_REQUIRE(layout == 0 || layout == 1, "layout must be 0 (full) or 1 (half)");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_velocity_f32(p, dk, out, layout, component, fac, s),
+                       fbi_velocity_f64(p, dk, out, layout, component, fac, s));
+}
+int fb_potential_k(fb_plan* p, const void* dk, void* out, int layout, void* stream) {
+    FB_REQUIRE(p && dk && out, "null pointer");
+    FB_REQUIRE(layout == 0 || layout == 1, "layout must be 0 (full) or 1 (half)");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_potential_f32(p, dk, out, layout, s), fbi_potential_f64(p, dk, out, layout, s));
+}
+int fb_lognormal(fb_plan* p, const void* in, void* out, double* mean_out, void* stream) {
+    FB_REQUIRE(p && in && out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_lognormal_f32(p, in, out, mean_out, s), fbi_lognormal_f64(p, in, out, mean_out, s));
+}
+int fb_redshift_space(fb_plan* p, const void* delta, const void* vz, const void* noise, void* out, double Hz,
+                      double sigma_nl, uint64_t seed, void* stream) {
+    FB_REQUIRE(p && delta && vz && out, "null pointer");
+    FB_REQUIRE(Hz > 0, "Hz must be positive");
+    FB_REQUIRE(out != delta && out != vz, "redshift_space is out of place");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_rsd_f32(p, delta, vz, noise, out, Hz, sigma_nl, seed, s),
+                       fbi_rsd_f64(p, delta, vz, noise, out, Hz, sigma_nl, seed, s));
+}
+int fb_sum_real(fb_plan* p, const void* x, int squared, double* out, void* stream) {
+    FB_REQUIRE(p && x && out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_sum_real_f32(p, x, squared, out, s), fbi_sum_real_f64(p, x, squared, out, s));
+}
+int fb_sumsq_half(fb_plan* p, const void* h, double* out, void* stream) {
+    FB_REQUIRE(p && h && out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_sumsq_half_f32(p, h, out, s), fbi_sumsq_half_f64(p, h, out, s));
+}
+int fb_expand_half(fb_plan* p, const void* half, void* full, void* stream) {
+    FB_REQUIRE(p && half && full, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_expand_half_f32(p, half, full, s), fbi_expand_half_f64(p, half, full, s));
+}
+int fb_crop_full(fb_plan* p, const void* full, void* half, void* stream) {
+    FB_REQUIRE(p && half && full, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_crop_full_f32(p, full, half, s), fbi_crop_full_f64(p, full, half, s));
+}
+
+int fb_malloc(void** dev_ptr, size_t bytes) {
+    FB_REQUIRE(dev_ptr, "null pointer");
+    FB_HIP(hipMalloc(dev_ptr, bytes ? bytes : 1));
+    return FB_OK;
+}
+int fb_free(void* dev_ptr) {
+    if (dev_ptr) FB_HIP(hipFree(dev_ptr));
+    return FB_OK;
+}
+int fb_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    FB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    FB_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return FB_OK;
+}
+int fb_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    FB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    FB_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return FB_OK;
+}
+int fb_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    FB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FB_OK;
+}
+int fb_stream_sync(void* stream) {
+    FB_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return FB_OK;
+}
+
+}  // extern "C"

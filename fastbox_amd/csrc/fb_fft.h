@@ -1,0 +1,134 @@
+// Stockham auto-sort FFT building blocks for gfx950 (wave64, LDS exchange).
+//
+// Replaces numpy.fft.ifftn / fftn on the reference hot path
+// (fastbox/box.py:187, 193, 246, 337, 380, 654, 736).
+//
+// Model: a line of N points is owned by TPL = N/E threads; thread t keeps the
+// E points  x[t + e*TPL]  (e = 0..E-1) in registers.  A stage of radix R with
+// p = product of the radices already done performs, per thread, E/R
+// butterflies i = t + m*TPL:
+//      u[q]  = x[i + q*N/R] * w_{pR}^{q (i mod p)}        (registers)
+//      u     = DFT_R(u)
+//      y[(i - i mod p) R + (i mod p) + q p] = u[q]        (LDS scatter)
+// and every thread then re-reads y[t + e*TPL].  The register<->position map
+// is therefore identical before the first and after the last stage: global
+// loads/stores of a pass never need a transposition of their own.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fb {
+
+template <typename T> struct alignas(2 * sizeof(T)) cx { T x, y; };
+
+template <typename T> __device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T> __device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename T> __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
+    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+template <typename T> __device__ __forceinline__ cx<T> cconj(cx<T> a) { return {a.x, -a.y}; }
+template <typename T> __device__ __forceinline__ cx<T> cscale(cx<T> a, T s) { return {a.x * s, a.y * s}; }
+// a * (SIGN * i)
+template <int SIGN, typename T> __device__ __forceinline__ cx<T> mul_si(cx<T> a) {
+    if constexpr (SIGN > 0) return {-a.y, a.x}; else return {a.y, -a.x};
+}
+
+// ---- small DFTs, natural-order output, w = exp(SIGN 2 pi i / R) ------------
+template <int SIGN, typename T> __device__ __forceinline__ void dft2(cx<T>& a, cx<T>& b) {
+    cx<T> s = a + b; b = a - b; a = s;
+}
+template <int SIGN, typename T>
+__device__ __forceinline__ void dft4(cx<T>& u0, cx<T>& u1, cx<T>& u2, cx<T>& u3) {
+    cx<T> t0 = u0 + u2, t1 = u0 - u2, t2 = u1 + u3, t3 = mul_si<SIGN>(u1 - u3);
+    u0 = t0 + t2; u1 = t1 + t3; u2 = t0 - t2; u3 = t1 - t3;
+}
+template <int SIGN, typename T> __device__ __forceinline__ void dft8(cx<T>* u) {
+    const T c = (T)0.70710678118654752440;
+    dft4<SIGN>(u[0], u[2], u[4], u[6]);      // even -> u0,u2,u4,u6 hold a0..a3
+    dft4<SIGN>(u[1], u[3], u[5], u[7]);      // odd  -> u1,u3,u5,u7 hold b0..b3
+    cx<T> b0 = u[1];
+    cx<T> b1 = {c * (u[3].x - SIGN * u[3].y), c * (SIGN * u[3].x + u[3].y)};
+    cx<T> b2 = mul_si<SIGN>(u[5]);
+    cx<T> b3 = {c * (-u[7].x - SIGN * u[7].y), c * (SIGN * u[7].x - u[7].y)};
+    cx<T> a0 = u[0], a1 = u[2], a2 = u[4], a3 = u[6];
+    u[0] = a0 + b0; u[4] = a0 - b0;
+    u[1] = a1 + b1; u[5] = a1 - b1;
+    u[2] = a2 + b2; u[6] = a2 - b2;
+    u[3] = a3 + b3; u[7] = a3 - b3;
+}
+template <int R, int SIGN, typename T> __device__ __forceinline__ void dft(cx<T>* u) {
+    static_assert(R == 2 || R == 4 || R == 8, "radix");
+    if constexpr (R == 2) dft2<SIGN>(u[0], u[1]);
+    else if constexpr (R == 4) dft4<SIGN>(u[0], u[1], u[2], u[3]);
+    else dft8<SIGN>(u);
+}
+
+constexpr int fb_min(int a, int b) { return a < b ? a : b; }
+constexpr int fb_max(int a, int b) { return a > b ? a : b; }
+
+// elements per thread for an n-point line
+constexpr int elems_per_thread(int n) { return fb_min(8, n); }
+
+// ---- LDS exchange layouts --------------------------------------------------
+// Strided-axis passes: tile[pos][col], col fastest.  A 16-lane (fp32) or
+// 8-lane (fp64) group always touches one contiguous 128-byte row, so both the
+// scattered writes and the linear reads are bank-conflict free.
+template <typename T, int TZ> struct TileLayout {
+    cx<T>* base; int col;
+    __device__ __forceinline__ cx<T>& at(int pos) const { return base[pos * TZ + col]; }
+};
+// Contiguous-axis passes: one line per thread group, one pad element every 8
+// so that the radix-8 first-stage scatter (lane stride 8 elements) spreads
+// over all banks.
+template <typename T> struct LineLayout {
+    cx<T>* base;
+    static __host__ __device__ constexpr int padded(int n) { return n + (n >> 3) + 1; }
+    __device__ __forceinline__ cx<T>& at(int pos) const { return base[pos + (pos >> 3)]; }
+};
+
+// ---- the stages --------------------------------------------------------------
+// tw: LDS table of forward twiddles W_M^j = exp(-2 pi i j / M), M = N * TWS.
+template <typename T, int N, int E, int SIGN, int TWS, int P, class Layout>
+__device__ __forceinline__ void fft_stages(cx<T> (&v)[E], const int t, const cx<T>* __restrict__ tw,
+                                           const Layout& lds) {
+    constexpr int REM = N / P;
+    constexpr int R = REM >= 8 ? 8 : REM;
+    constexpr int NB = E / R;
+    constexpr int TPL = N / E;
+    static_assert(E % R == 0, "radix must divide elements per thread");
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+        cx<T> u[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) u[q] = v[m + q * NB];
+        if constexpr (P > 1) {
+            const int k = (t + m * TPL) & (P - 1);
+#pragma unroll
+            for (int q = 1; q < R; ++q) {
+                cx<T> w = tw[q * k * (N / (P * R)) * TWS];
+                if constexpr (SIGN > 0) w.y = -w.y;
+                u[q] = cmul(u[q], w);
+            }
+        }
+        dft<R, SIGN>(u);
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[m + q * NB] = u[q];
+    }
+    if constexpr (P * R < N) {
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const int i = t + m * TPL;
+            const int k = i & (P - 1);
+            const int j = (i - k) * R + k;
+#pragma unroll
+            for (int q = 0; q < R; ++q) lds.at(j + q * P) = v[m + q * NB];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = lds.at(t + e * TPL);
+        __syncthreads();
+        fft_stages<T, N, E, SIGN, TWS, P * R, Layout>(v, t, tw, lds);
+    }
+}
+
+}  // namespace fb

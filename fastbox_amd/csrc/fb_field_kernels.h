@@ -1,0 +1,453 @@
+// Element-wise k-space / real-space kernels of the density-field hot path.
+// Every kernel cites the reference expression (fastbox/box.py) it replaces.
+//
+// Layouts (z fastest, C order like the reference's numpy arrays):
+//   real  : T      [N][N][N]
+//   half  : cx<T>  [N][N][NZP]   k_z = 0..N/2 stored (NZV = N/2+1), row pitch NZP
+//   full  : cx<T>  [N][N][N]
+#pragma once
+#include "fb_fft.h"
+
+namespace fb {
+
+#define FB_TWO_PI 6.283185307179586
+
+__device__ __forceinline__ int mode_of(int i, int N) { return i < (N >> 1) ? i : i - N; }   // box.py:119
+__device__ __forceinline__ int mirror_of(int i, int N) { return i == 0 ? 0 : N - i; }
+
+// Geometry tables computed on the host with the reference's own numpy
+// expressions, so that |k| is bit-identical to box.py:125-127.
+struct KGeom {
+    const double* axis2;   // [3][N]  (m/L_a)**2                 box.py:125-127
+    const double* ksc;     // [3][N]  m * (2 pi / L_a)            box.py:254-256
+    const double* kpar;    // [N]     2 pi m / Lz                 box.py:375
+    int N, NZV, NZP;
+};
+
+__device__ __forceinline__ void fb_sincospi(float x, float* s, float* c) { sincospif(x, s, c); }
+__device__ __forceinline__ void fb_sincospi(double x, double* s, double* c) { sincospi(x, s, c); }
+__device__ __forceinline__ void fb_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+__device__ __forceinline__ void fb_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+
+__device__ __forceinline__ double kmag_exact(const KGeom& g, int i, int j, int l) {
+#pragma clang fp contract(off)
+    double s = (g.axis2[i] + g.axis2[g.N + j]) + g.axis2[2 * g.N + l];
+    return FB_TWO_PI * sqrt(s);
+}
+__device__ __forceinline__ double kperp_exact(const KGeom& g, int i, int j) {   // box.py:374
+#pragma clang fp contract(off)
+    double s = g.axis2[i] + g.axis2[g.N + j];
+    return FB_TWO_PI * sqrt(s);
+}
+__device__ __forceinline__ int shell_of(int i, int j, int l, int N) {
+    int a = mode_of(i, N), b = mode_of(j, N), c = mode_of(l, N);
+    return a * a + b * b + c * c;
+}
+
+template <typename T> __device__ __forceinline__ T nan_to_num(T v) {   // np.nan_to_num defaults
+    if (v != v) return (T)0;
+    if (sizeof(T) == 4) { if (v > (T)3.4028234663852886e38) return (T)3.4028234663852886e38;
+                          if (v < (T)-3.4028234663852886e38) return (T)-3.4028234663852886e38; }
+    else { if (v > (T)1.7976931348623157e308) return (T)1.7976931348623157e308;
+           if (v < (T)-1.7976931348623157e308) return (T)-1.7976931348623157e308; }
+    return v;
+}
+
+// ---- sqrt(P(k) boxfactor) source ------------------------------------------------------
+template <typename T> struct AmpSrc {
+    const T* shell;   // [n^2] for cubic boxes, or
+    const T* dense;   // [N][N][NZP] evaluated per stored mode on the host
+};
+template <typename T>
+__device__ __forceinline__ T amp_at(const AmpSrc<T>& a, const KGeom& g, int i, int j, int l) {
+    if (a.shell) return a.shell[shell_of(i, j, l, g.N)];
+    return a.dense[((long long)i * g.N + j) * g.NZP + l];
+}
+
+// ---- Gaussian field, parity mode ---------------------------------------------------------
+// box.py:174-187: X = (re + i im) sqrt(pk); delta_x = Re ifftn(X).  Re ifftn(X) is
+// ifftn of the Hermitian part (X(k) + conj X(-k))/2, which is what is stored here.
+template <typename T>
+__global__ void k_colour_noise(const T* __restrict__ re, const T* __restrict__ im, cx<T>* __restrict__ out,
+                               AmpSrc<T> amp, KGeom g) {
+    const int N = g.N;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y, i = blockIdx.z;
+    if (l >= g.NZV) return;
+    const long long a = ((long long)i * N + j) * N + l;
+    const long long b = ((long long)mirror_of(i, N) * N + mirror_of(j, N)) * N + mirror_of(l, N);
+    const T A = (T)0.5 * amp_at(amp, g, i, j, l);
+    out[((long long)i * N + j) * g.NZP + l] = cx<T>{A * (re[a] + re[b]), A * (im[a] - im[b])};
+}
+
+// ---- Gaussian field, throughput mode (counter-based RNG) ---------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+template <typename T> __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, T& g0, T& g1) {
+    const T u1 = ((T)a + (T)0.5) * (T)2.3283064365386963e-10;
+    const T u2 = ((T)b + (T)0.5) * (T)2.3283064365386963e-10;
+    const T r = sqrt((T)-2 * log(u1));
+    T s, c;
+    fb_sincospi((T)2 * u2, &s, &c);
+    g0 = r * c; g1 = r * s;
+}
+// Statistically identical to box.py:174-187 without the mirrored draw: a stored mode
+// gets A (g1 + i g2)/sqrt(2); on the self-mirrored planes k_z = 0, N/2 it gets
+// A (g1 + i g2) and the c2r pass's Hermitian projection halves the variance.
+template <typename T>
+__global__ void k_colour_philox(cx<T>* __restrict__ out, AmpSrc<T> amp, KGeom g,
+                                uint32_t seed_lo, uint32_t seed_hi, uint32_t real_lo, uint32_t real_hi) {
+    const int N = g.N;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y, i = blockIdx.z;
+    if (l >= g.NZV) return;
+    const unsigned long long idx = ((unsigned long long)i * N + j) * g.NZV + l;
+    uint32_t o[4];
+    philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), real_lo, real_hi, seed_lo, seed_hi, o);
+    T g0, g1;
+    box_muller<T>(o[0], o[1], g0, g1);
+    T A = amp_at(amp, g, i, j, l);
+    if (l != 0 && l != (N >> 1)) A *= (T)0.70710678118654752440;
+    out[((long long)i * N + j) * g.NZP + l] = cx<T>{A * g0, A * g1};
+}
+
+// ---- shell binning of |delta_k|^2 --------------------------------------------------------------
+// box.py:741-764.  idx = np.digitize(k, bins) = number of edges <= k.  For cubic boxes the
+// bin is a step function of the integer shell n^2, given as thresholds thr[b] = first
+// n^2 whose |k| reaches edge b; the (rare) shells whose |k| is within rounding of an
+// edge are listed in amb[] and decided with the exact fp64 expression.
+struct BinGeom {
+    const double* bins;   // [nbins] edges, ascending
+    const int* thr;       // [nbins] or null (non-cubic: always exact)
+    int nbins;
+    int namb;
+    int amb[8];
+};
+#define FB_BIN_WAVES 4
+
+__device__ __forceinline__ int bin_exact(const double* bins, int nbins, double k) {
+    int b = 0;
+    for (int q = 0; q < nbins; ++q) b += (bins[q] <= k) ? 1 : 0;
+    return b;
+}
+__device__ __forceinline__ int bin_of_mode(const BinGeom& bg, const KGeom& g, const double* lbins,
+                                           const int* lthr, int i, int j, int l) {
+    if (bg.thr) {
+        const int n2 = shell_of(i, j, l, g.N);
+        bool amb = false;
+        for (int q = 0; q < bg.namb; ++q) amb |= (bg.amb[q] == n2);
+        if (!amb) {
+            int lo = 0, hi = bg.nbins;          // count of thr[] <= n2 (thr ascending)
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (lthr[mid] <= n2) lo = mid + 1; else hi = mid; }
+            return lo;
+        }
+    }
+    return bin_exact(lbins, bg.nbins, kmag_exact(g, i, j, l));
+}
+
+// partial[block][2*nbins] = (sum w p, sum w p^2), p = |delta_k|^2, w = multiplicity of the
+// stored mode in the full grid (2 for 0 < k_z < N/2).  Deterministic: lane-group private
+// LDS slots, fixed-order reduction.
+template <typename T>
+__global__ __launch_bounds__(64 * FB_BIN_WAVES)
+void k_bin_half(const cx<T>* __restrict__ half, double* __restrict__ partial, KGeom g, BinGeom bg, int rep,
+                int full_layout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lbins = reinterpret_cast<double*>(smem);
+    double* acc = lbins + bg.nbins;                                   // [waves][nbins][rep][2]
+    int* lthr = reinterpret_cast<int*>(acc + FB_BIN_WAVES * bg.nbins * rep * 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int q = tid; q < bg.nbins; q += blockDim.x) { lbins[q] = bg.bins[q]; lthr[q] = bg.thr ? bg.thr[q] : 0; }
+    for (int q = tid; q < FB_BIN_WAVES * bg.nbins * rep * 2; q += blockDim.x) acc[q] = 0.0;
+    __syncthreads();
+    double* my = acc + (size_t)wave * bg.nbins * rep * 2;
+    const int slot = lane & (rep - 1);
+    const long long nrows = (long long)g.N * g.N;
+    for (long long row = (long long)blockIdx.x * FB_BIN_WAVES + wave; row < nrows;
+         row += (long long)gridDim.x * FB_BIN_WAVES) {
+        const int i = (int)(row / g.N), j = (int)(row % g.N);
+        const int nz = full_layout ? g.N : g.NZV, pitch = full_layout ? g.N : g.NZP;
+        for (int l = lane; l < nz; l += 64) {
+            const int b = bin_of_mode(bg, g, lbins, lthr, i, j, l);
+            if (b < bg.nbins) {
+                const cx<T> d = half[row * pitch + l];
+                const double p = (double)(d.x * d.x + d.y * d.y);
+                const double w = (full_layout || l == 0 || l == (g.N >> 1)) ? 1.0 : 2.0;
+                atomicAdd(&my[(b * rep + slot) * 2 + 0], w * p);
+                atomicAdd(&my[(b * rep + slot) * 2 + 1], w * p * p);
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < 2 * bg.nbins; q += blockDim.x) {
+        const int b = q >> 1, c = q & 1;
+        double s = 0.0;
+        for (int w = 0; w < FB_BIN_WAVES; ++w)
+            for (int r = 0; r < rep; ++r) s += acc[(((size_t)w * bg.nbins + b) * rep + r) * 2 + c];
+        partial[(size_t)blockIdx.x * 2 * bg.nbins + q] = s;
+    }
+}
+
+static __global__ void k_bin_finish(const double* __restrict__ partial, int nblocks, int nvals, double* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nvals) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * nvals + q];
+    out[q] = s;
+}
+
+// number of full-grid modes per bin (data independent; done once per bin set)
+static __global__ void k_bin_count(unsigned long long* __restrict__ counts, KGeom g, BinGeom bg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lbins = reinterpret_cast<double*>(smem);
+    unsigned long long* lc = reinterpret_cast<unsigned long long*>(lbins + bg.nbins);
+    int* lthr = reinterpret_cast<int*>(lc + bg.nbins);
+    const int tid = threadIdx.x;
+    for (int q = tid; q < bg.nbins; q += blockDim.x) { lbins[q] = bg.bins[q]; lc[q] = 0; lthr[q] = bg.thr ? bg.thr[q] : 0; }
+    __syncthreads();
+    const long long nrows = (long long)g.N * g.N;
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int i = (int)(row / g.N), j = (int)(row % g.N);
+        for (int l = tid; l < g.NZV; l += blockDim.x) {
+            const int b = bin_of_mode(bg, g, lbins, lthr, i, j, l);
+            if (b < bg.nbins) atomicAdd(&lc[b], (l == 0 || l == (g.N >> 1)) ? 1ull : 2ull);
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < bg.nbins; q += blockDim.x) if (lc[q]) atomicAdd(&counts[q], lc[q]);
+}
+
+// ---- reductions ---------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// block partial sums of f(x); OP 0: x, 1: x^2, 2: exp(x) (also written to out)
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void k_reduce_real(const T* __restrict__ in, T* __restrict__ out, long long n,
+                                                      double* __restrict__ partial) {
+    __shared__ double ws[4];
+    double s = 0.0;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
+        T x = in[q];
+        if (OP == 1) x = x * x;
+        if (OP == 2) { x = exp(x); out[q] = x; }
+        s += (double)x;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+// sum over the FULL grid of |delta_k|^2 from a half spectrum (box.py:946)
+template <typename T>
+__global__ __launch_bounds__(256) void k_sumsq_half(const cx<T>* __restrict__ half, KGeom g, double* __restrict__ partial) {
+    __shared__ double ws[4];
+    double s = 0.0;
+    const long long nrows = (long long)g.N * g.N;
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x)
+        for (int l = threadIdx.x; l < g.NZV; l += blockDim.x) {
+            const cx<T> d = half[row * g.NZP + l];
+            const double p = (double)d.x * d.x + (double)d.y * d.y;
+            s += (l == 0 || l == (g.N >> 1)) ? p : 2.0 * p;
+        }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+// y = a x + b   (log-normal finish: exp(d)/mean - 1, box.py:458-459)
+template <typename T>
+__global__ void k_affine(T* __restrict__ x, long long n, T a, T b) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x)
+        x[q] = x[q] * a + b;
+}
+
+// ---- k-space multipliers ---------------------------------------------------------------------------
+// box.py:374-379 (apply_transfer_fn) and :651-653 (smooth_field).
+enum { FILT_TABLE = 0, FILT_BEAM_HIGHPASS = 1, FILT_WEDGE = 2, FILT_TOPHAT = 3 };
+struct FilterSpec {
+    int kind;
+    double p[4];
+    const void* table;   // FILT_TABLE: real multiplier in the layout of the field
+};
+// BEAM_HIGHPASS: (1 - exp(-0.5 (|kpar|/p0)^p2)) [p0 > 0]  *  exp(-0.5 (kperp/p1)^2) [p1 > 0]
+// WEDGE       : 0 where |kpar| < p0 * kperp + p1, else 1
+// TOPHAT      : 3 (sin x - x cos x)/x^3, x = |k| p0   (NaN at k=0 -> 0 after nan_to_num)
+template <typename T>
+__device__ __forceinline__ T filter_value(const FilterSpec& f, const KGeom& g, int i, int j, int l, long long idx) {
+    if (f.kind == FILT_TABLE) return reinterpret_cast<const T*>(f.table)[idx];
+    if (f.kind == FILT_TOPHAT) {
+        const T x = (T)(kmag_exact(g, i, j, l) * f.p[0]);
+        T s, c;
+        fb_sincos(x, &s, &c);
+        return ((T)3 / (x * x * x)) * (s - x * c);
+    }
+    const T kperp = (T)kperp_exact(g, i, j);
+    const T kpar = (T)g.kpar[l];
+    if (f.kind == FILT_WEDGE) return (fabs(kpar) < (T)f.p[0] * kperp + (T)f.p[1]) ? (T)0 : (T)1;
+    T v = (T)1;
+    if (f.p[0] > 0) {
+        const T r = fabs(kpar) / (T)f.p[0];
+        const T rp = (f.p[2] == 2.0) ? r * r : pow(r, (T)f.p[2]);
+        v *= (T)1 - exp((T)-0.5 * rp);
+    }
+    if (f.p[1] > 0) { const T r = kperp / (T)f.p[1]; v *= exp((T)-0.5 * r * r); }
+    return v;
+}
+// out = nan_to_num(in * T(k)); pitch = NZP (half) or N (full); nz = stored k_z count
+template <typename T>
+__global__ void k_apply_filter(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, FilterSpec f, KGeom g,
+                               int pitch, int nz) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y, i = blockIdx.z;
+    if (l >= nz) return;
+    const long long idx = ((long long)i * g.N + j) * pitch + l;
+    const T m = filter_value<T>(f, g, i, j, l, idx);
+    const cx<T> d = in[idx];
+    out[idx] = cx<T>{nan_to_num(d.x * m), nan_to_num(d.y * m)};
+}
+
+// ---- velocity / potential ------------------------------------------------------------------------------
+// box.py:251-284: A_c = i delta_k k_c / k^2, NaN -> 0, plane m_c = -N/2 zeroed, times fac.
+template <typename T>
+__global__ void k_velocity(const cx<T>* __restrict__ dk, cx<T>* __restrict__ out, KGeom g, int comp, double fac,
+                           int pitch, int nz) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y, i = blockIdx.z;
+    if (l >= nz) return;
+    const long long idx = ((long long)i * g.N + j) * pitch + l;
+    const int ic = comp == 0 ? i : (comp == 1 ? j : l);
+    const double k = kmag_exact(g, i, j, l);
+    const double k2 = k * k;
+    const cx<T> d = dk[idx];
+    cx<T> v{0, 0};
+    if (k2 > 0.0 && ic != (g.N >> 1)) {
+        const double kc = g.ksc[comp * g.N + ic];
+        // (i d) * kc / k2  with i d = (-d.y, d.x)
+        v.x = (T)(((double)(-d.y) * kc) / k2 * fac);
+        v.y = (T)(((double)d.x * kc) / k2 * fac);
+    }
+    out[idx] = v;
+}
+// box.py:347-348
+template <typename T>
+__global__ void k_potential(const cx<T>* __restrict__ dk, cx<T>* __restrict__ out, KGeom g, int pitch, int nz) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y, i = blockIdx.z;
+    if (l >= nz) return;
+    const long long idx = ((long long)i * g.N + j) * pitch + l;
+    const double k = kmag_exact(g, i, j, l);
+    const double k2 = k * k;
+    const cx<T> d = dk[idx];
+    cx<T> v{0, 0};
+    if (i | j | l) { v.x = (T)((double)d.x / k2); v.y = (T)((double)d.y / k2); }
+    out[idx] = v;
+}
+
+// ---- layout helpers ----------------------------------------------------------------------------------------
+// full[k] = half[k] (k_z <= N/2) or conj(half[-k]) -- Hermitian extension for host views of delta_k
+template <typename T>
+__global__ void k_expand_half(const cx<T>* __restrict__ half, cx<T>* __restrict__ full, KGeom g) {
+    const int N = g.N;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y, i = blockIdx.z;
+    if (l >= N) return;
+    cx<T> v;
+    if (l <= (N >> 1)) v = half[((long long)i * N + j) * g.NZP + l];
+    else v = cconj(half[((long long)mirror_of(i, N) * N + mirror_of(j, N)) * g.NZP + (N - l)]);
+    full[((long long)i * N + j) * N + l] = v;
+}
+template <typename T>
+__global__ void k_crop_full(const cx<T>* __restrict__ full, cx<T>* __restrict__ half, KGeom g) {
+    const int N = g.N;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y, i = blockIdx.z;
+    if (l >= g.NZV) return;
+    half[((long long)i * N + j) * g.NZP + l] = full[((long long)i * N + j) * N + l];
+}
+
+// ---- redshift-space remap ------------------------------------------------------------------------------------
+// box.py:412-437, one workgroup per line of sight: s = z - (v + sigma n)/H, periodic wrap,
+// sort (s, delta) in LDS (bitonic), then for every grid point the scipy griddata/np.interp
+// rule: left bracket by bisection, slope*(x - x_lo) + y_lo, exact hit -> y, outside -> fill.
+template <typename T>
+__global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise,
+                      T* __restrict__ out, const double* __restrict__ zgrid, int N, double Hz, double sigma_nl,
+                      uint32_t seed_lo, uint32_t seed_hi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* key = reinterpret_cast<double*>(smem);   // [N]
+    double* val = key + N;                            // [N]
+    const long long los = blockIdx.x;
+    const T* d = delta + los * N;
+    const T* v = vz + los * N;
+    const double zmin = zgrid[0], zmax = zgrid[N - 1];
+    const double len = zmax - zmin;
+    for (int m = threadIdx.x; m < N; m += blockDim.x) {
+#pragma clang fp contract(off)
+        double vel = (double)v[m];
+        if (sigma_nl > 0.0) {
+            double n;
+            if (noise) n = (double)noise[los * N + m];
+            else {
+                uint32_t o[4];
+                const unsigned long long idx = (unsigned long long)los * N + m;
+                philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), 0x52534421u, 0u, seed_lo, seed_hi, o);
+                double g0, g1; box_muller<double>(o[0], o[1], g0, g1); n = g0;
+            }
+            vel = vel + sigma_nl * n;
+        }
+        double s = zgrid[m] - vel / Hz;
+        double r = fmod(s - zmin, len);               // numpy % : result takes the divisor's sign
+        if (r != 0.0) { if (r < 0.0) r += len; } else r = 0.0;
+        key[m] = r + zmin;
+        val[m] = (double)d[m];
+    }
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int m = threadIdx.x; m < N; m += blockDim.x) {
+                const int p = m ^ j;
+                if (p > m) {
+                    const bool up = (m & k) == 0;
+                    const double a = key[m], b = key[p];
+                    if ((a > b) == up) { key[m] = b; key[p] = a; const double t = val[m]; val[m] = val[p]; val[p] = t; }
+                }
+            }
+            __syncthreads();
+        }
+    const double fill = 0.5 * ((double)d[0] + (double)d[N - 1]);
+    for (int m = threadIdx.x; m < N; m += blockDim.x) {
+#pragma clang fp contract(off)
+        const double x = zgrid[m];
+        double y;
+        if (x < key[0] || x > key[N - 1]) y = fill;
+        else {
+            int lo = 0, hi = N;                        // count of key[] <= x
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[mid] <= x) lo = mid + 1; else hi = mid; }
+            const int jx = lo - 1;
+            if (jx == N - 1 || key[jx] == x) y = val[jx];
+            else {
+                const double slope = (val[jx + 1] - val[jx]) / (key[jx + 1] - key[jx]);
+                y = slope * (x - key[jx]) + val[jx];
+                if (y != y) {
+                    y = slope * (x - key[jx + 1]) + val[jx + 1];
+                    if (y != y && val[jx] == val[jx + 1]) y = val[jx];
+                }
+            }
+        }
+        out[los * N + m] = (T)y;
+    }
+}
+
+}  // namespace fb

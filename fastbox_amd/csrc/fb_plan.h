@@ -1,0 +1,78 @@
+// Internal plan object behind the opaque `fb_plan*` of include/fastbox_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#define FB_OK 0
+#define FB_ERR_INVALID -1
+#define FB_ERR_HIP -2
+#define FB_ERR_UNSUPPORTED -3
+#define FB_ERR_NOMEM -4
+#define FB_ERR_STATE -5
+
+struct fb_plan {
+    int N = 0;
+    int prec = 4;            // bytes per real: 4 (float) or 8 (double)
+    double L[3] = {0, 0, 0};
+    int device = 0;
+    int NZV = 0;             // stored k_z modes of a half spectrum: N/2+1
+    int NZP = 0;             // row pitch of a half spectrum (complex elements)
+    int cubic = 0;           // Lx == Ly == Lz (integer shells usable)
+
+    void* tw = nullptr;      // forward twiddles W_N^j, j < N, in plan precision
+    double* axis2 = nullptr; // [3][N] (m_i / L_a)^2 exactly as numpy computes it (box.py:125-127)
+    double* kpar = nullptr;  // [N]  2 pi m / Lz
+    double* ksc = nullptr;   // [3][N] m_i * (2 pi / L_a)  (velocity numerators, box.py:254-256)
+    double* zgrid = nullptr; // [N]  self.z
+
+    // sqrt(P(k) boxfactor) lookup (box.py:161-176)
+    void* amp_shell = nullptr;   // [nshell] plan precision, index n^2 = i^2+j^2+l^2 (cubic only)
+    int64_t nshell = 0;
+    const void* amp_dense = nullptr;  // caller-owned [N][N][NZP]
+
+    // P(k) binning (box.py:745-764)
+    double* bins = nullptr;      // [nbins] edges
+    int nbins = 0;
+    int* thr = nullptr;          // [FB_MAX_BINS] shell thresholds (cubic boxes)
+    int use_thr = 0;             // 0: decide every mode with the exact fp64 |k|
+    int namb = 0;
+    int amb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long* counts = nullptr;  // [FB_MAX_BINS] device
+    double counts_host[256];
+    double* partials = nullptr;  // [prow][3*FB_MAX_BINS] per-workgroup partial sums
+    int prow = 0;
+    double* scratch = nullptr;   // small reduction scratch [FB_SCRATCH]
+};
+
+#define FB_MAX_BINS 256
+#define FB_SCRATCH 8192
+
+void fb_set_error(const std::string& msg);
+int fb_hip_check(hipError_t e, const char* what);
+#define FB_HIP(x) do { int _r = fb_hip_check((x), #x); if (_r) return _r; } while (0)
+#define FB_LAUNCH_CHECK(name) do { int _r = fb_hip_check(hipGetLastError(), name); if (_r) return _r; } while (0)
+
+// ---- per-precision launchers (fb_fft_launch.inc, fb_field_launch.inc) ------------
+#define FB_DECL(sfx) \
+    int fbi_fft_c2c_##sfx(fb_plan* p, void* data, int sign, double scale, hipStream_t s); \
+    int fbi_fft_r2c_##sfx(fb_plan* p, const void* real_in, void* half_out, int pre_exp, hipStream_t s); \
+    int fbi_fft_c2r_##sfx(fb_plan* p, void* half_inout, void* real_out, double scale, hipStream_t s); \
+    int fbi_set_amp_shells_##sfx(fb_plan* p, const double* amp, int64_t n); \
+    int fbi_colour_noise_##sfx(fb_plan* p, const void* re, const void* im, void* out, hipStream_t s); \
+    int fbi_colour_philox_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* out, hipStream_t s); \
+    int fbi_bin_power_##sfx(fb_plan* p, const void* spec, int layout, double* sums_dev, hipStream_t s); \
+    int fbi_apply_filter_##sfx(fb_plan* p, const void* in, void* out, int layout, int kind, const double* prm, \
+                               const void* table, hipStream_t s); \
+    int fbi_velocity_##sfx(fb_plan* p, const void* dk, void* out, int layout, int comp, double fac, hipStream_t s); \
+    int fbi_potential_##sfx(fb_plan* p, const void* dk, void* out, int layout, hipStream_t s); \
+    int fbi_lognormal_##sfx(fb_plan* p, const void* in, void* out, double* mean_out, hipStream_t s); \
+    int fbi_rsd_##sfx(fb_plan* p, const void* d, const void* vz, const void* noise, void* out, double Hz, \
+                      double sigma, uint64_t seed, hipStream_t s); \
+    int fbi_sum_real_##sfx(fb_plan* p, const void* x, int squared, double* out, hipStream_t s); \
+    int fbi_sumsq_half_##sfx(fb_plan* p, const void* h, double* out, hipStream_t s); \
+    int fbi_expand_half_##sfx(fb_plan* p, const void* h, void* f, hipStream_t s); \
+    int fbi_crop_full_##sfx(fb_plan* p, const void* f, void* h, hipStream_t s);
+FB_DECL(f32)
+FB_DECL(f64)
+int fbi_bin_count(fb_plan* p, hipStream_t s);

@@ -1,0 +1,332 @@
+"""
+HBM-resident fields and the per-box engine that drives libfastbox_hip.
+
+``Engine`` owns one ``fb_plan`` (grid geometry, twiddles, lookup tables) and a
+small pool of device buffers; every method is a thin call into the C ABI.
+``DeviceArray`` is what CosmoBox methods return: the field stays in HBM and is
+only copied to the host (as float64 / complex128, the reference's dtypes) when
+numpy touches it (``np.asarray``, indexing, ufuncs).
+"""
+import ctypes
+
+import numpy as np
+from numpy.lib.mixins import NDArrayOperatorsMixin
+
+from . import _lib
+
+REAL, HALF, FULL = "real", "half", "full"
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class _Buffer(object):
+    """Raw device allocation returned to the engine's pool when dropped."""
+
+    __slots__ = ("ptr", "nbytes", "pool")
+
+    def __init__(self, ptr, nbytes, pool):
+        self.ptr, self.nbytes, self.pool = ptr, nbytes, pool
+
+    def __del__(self):
+        pool = self.pool
+        if pool is not None and self.ptr:
+            pool.setdefault(self.nbytes, []).append(self.ptr)
+            self.ptr = None
+
+
+class DeviceArray(NDArrayOperatorsMixin):
+    """A (N,N,N) field living in device memory.
+
+    kind 'real': T[N][N][N]; 'half': Hermitian half spectrum (host view is the
+    full (N,N,N) complex array); 'full': complex [N][N][N].
+    """
+
+    __array_priority__ = 1000
+
+    def __init__(self, engine, kind, buf, as_complex=False):
+        self.engine, self.kind, self._buf = engine, kind, buf
+        self._host = None
+        self._as_complex = as_complex   # real field presented as complex (apply_transfer_fn returns complex)
+        N = engine.N
+        self.shape = (N, N, N)
+        self.ndim = 3
+        self.size = N ** 3
+
+    @property
+    def ptr(self):
+        return self._buf.ptr
+
+    @property
+    def dtype(self):
+        return np.dtype(np.float64 if (self.kind == REAL and not self._as_complex) else np.complex128)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def host(self):
+        """Host copy in the reference's dtype (cached; read-only snapshot)."""
+        if self._host is None:
+            h = self.engine.download(self)
+            if self._as_complex:
+                h = h.astype(np.complex128)
+            h.setflags(write=False)
+            self._host = h
+        return self._host
+
+    def invalidate(self):
+        self._host = None
+
+    def __array__(self, dtype=None, copy=None):
+        h = self.host()
+        if dtype is not None and np.dtype(dtype) != h.dtype:
+            return h.astype(dtype)
+        return h
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        args = [x.host() if isinstance(x, DeviceArray) else x for x in inputs]
+        if "out" in kwargs:
+            return NotImplemented
+        return getattr(ufunc, method)(*args, **kwargs)
+
+    def __getitem__(self, idx):
+        return self.host()[idx]
+
+    @property
+    def real(self):
+        if self.kind == REAL:
+            return DeviceArray(self.engine, REAL, self._buf)
+        return self.host().real
+
+    @property
+    def imag(self):
+        return self.host().imag
+
+    def flatten(self):
+        return self.host().flatten()
+
+    def copy(self):
+        return np.array(self.host())
+
+    def __repr__(self):
+        return "DeviceArray(kind=%s, shape=%s, precision=%s)" % (self.kind, self.shape, self.engine.precision)
+
+
+class Engine(object):
+    """One fb_plan + buffer pool.  All field arguments are DeviceArrays."""
+
+    def __init__(self, N, L, axis2, ksc, kpar, zgrid, precision="f32", device=0, stream=None):
+        if precision not in ("f32", "f64"):
+            raise ValueError("precision must be 'f32' or 'f64'")
+        self.lib = _lib.load()
+        self.N = int(N)
+        self.precision = precision
+        self.rdtype = np.float32 if precision == "f32" else np.float64
+        self.cdtype = np.complex64 if precision == "f32" else np.complex128
+        self.stream = ctypes.c_void_p(stream) if stream else None
+        self._pool = {}
+        self._plan = ctypes.c_void_p()
+        tabs = [np.ascontiguousarray(t, dtype=np.float64) for t in (axis2, ksc, kpar, zgrid)]
+        assert tabs[0].size == 3 * N and tabs[1].size == 3 * N and tabs[2].size == N and tabs[3].size == N
+        _lib.call("fb_plan_create", ctypes.byref(self._plan), self.N, float(L[0]), float(L[1]), float(L[2]),
+                  4 if precision == "f32" else 8, int(device),
+                  *[t.ctypes.data_as(_lib.P_double) for t in tabs])
+        self.pitch = self.lib.fb_half_pitch(self._plan)
+        self.nbytes = {REAL: self.lib.fb_real_bytes(self._plan), HALF: self.lib.fb_half_bytes(self._plan),
+                       FULL: self.lib.fb_full_bytes(self._plan)}
+        self._amp_dense = None
+        self._bins_key = None
+
+    def close(self):
+        if getattr(self, "_plan", None) is not None and self._plan:
+            self.sync()
+            for ptrs in self._pool.values():
+                for p in ptrs:
+                    self.lib.fb_free(ctypes.c_void_p(p))
+            self._pool = {}
+            self.lib.fb_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- memory ---------------------------------------------------------------
+    def _alloc_bytes(self, nbytes):
+        free = self._pool.get(nbytes)
+        if free:
+            return _Buffer(free.pop(), nbytes, self._pool)
+        p = ctypes.c_void_p()
+        _lib.call("fb_malloc", ctypes.byref(p), nbytes)
+        return _Buffer(p.value, nbytes, self._pool)
+
+    def empty(self, kind, as_complex=False):
+        return DeviceArray(self, kind, self._alloc_bytes(self.nbytes[kind]), as_complex)
+
+    def sync(self):
+        _lib.call("fb_stream_sync", self.stream)
+
+    def upload(self, arr, kind):
+        """Host ndarray (N,N,N) -> device.  kind REAL or FULL."""
+        N = self.N
+        a = np.asarray(arr)
+        if a.shape != (N, N, N):
+            raise ValueError("expected an array of shape %s, got %s" % ((N, N, N), a.shape))
+        a = np.ascontiguousarray(a, dtype=self.rdtype if kind == REAL else self.cdtype)
+        out = self.empty(kind)
+        _lib.call("fb_memcpy_h2d", out.ptr, _ptr(a), a.nbytes, self.stream)
+        return out
+
+    def upload_raw(self, a):
+        """Contiguous host array of any shape -> anonymous device buffer."""
+        a = np.ascontiguousarray(a)
+        buf = self._alloc_bytes(a.nbytes)
+        _lib.call("fb_memcpy_h2d", buf.ptr, _ptr(a), a.nbytes, self.stream)
+        return buf
+
+    def download(self, d):
+        N = self.N
+        if d.kind == HALF:
+            full = self.expand_half(d)
+            return self.download(full)
+        dt = self.rdtype if d.kind == REAL else self.cdtype
+        h = np.empty((N, N, N), dtype=dt)
+        _lib.call("fb_memcpy_d2h", _ptr(h), d.ptr, h.nbytes, self.stream)
+        return h.astype(np.float64 if d.kind == REAL else np.complex128)
+
+    def download_half_raw(self, d):
+        """Half spectrum as stored: (N, N, pitch) complex, columns >= N/2+1 are padding."""
+        h = np.empty((self.N, self.N, self.pitch), dtype=self.cdtype)
+        _lib.call("fb_memcpy_d2h", _ptr(h), d.ptr, h.nbytes, self.stream)
+        return h
+
+    def clone(self, d):
+        out = self.empty(d.kind, d._as_complex)
+        _lib.call("fb_memcpy_d2d", out.ptr, d.ptr, self.nbytes[d.kind], self.stream)
+        return out
+
+    # -- FFTs -------------------------------------------------------------------
+    def fft_r2c(self, real, pre_exp=False):
+        out = self.empty(HALF)
+        _lib.call("fb_fft_r2c", self._plan, real.ptr, out.ptr, 1 if pre_exp else 0, self.stream)
+        return out
+
+    def fft_c2r(self, half, scale=None, destroy=False, as_complex=False):
+        """Re ifftn; numpy's 1/N^3 unless `scale` is given.  `half` is preserved unless destroy."""
+        work = half if destroy else self.clone(half)
+        out = self.empty(REAL, as_complex)
+        _lib.call("fb_fft_c2r", self._plan, work.ptr, out.ptr,
+                  float(scale if scale is not None else 1.0 / self.N ** 3), self.stream)
+        return out
+
+    def fft_c2c(self, full, direction, scale=1.0, inplace=False):
+        out = full if inplace else self.clone(full)
+        _lib.call("fb_fft_c2c", self._plan, out.ptr, int(direction), float(scale), self.stream)
+        out.invalidate()
+        return out
+
+    def expand_half(self, half):
+        out = self.empty(FULL)
+        _lib.call("fb_expand_half", self._plan, half.ptr, out.ptr, self.stream)
+        return out
+
+    def crop_full(self, full):
+        out = self.empty(HALF)
+        _lib.call("fb_crop_full", self._plan, full.ptr, out.ptr, self.stream)
+        return out
+
+    # -- Gaussian realisation ----------------------------------------------------
+    def set_amplitude_shells(self, amp):
+        amp = np.ascontiguousarray(amp, dtype=np.float64)
+        self._amp_dense = None
+        _lib.call("fb_set_amplitude_shells", self._plan, amp.ctypes.data_as(_lib.P_double), amp.size)
+
+    def set_amplitude_dense(self, amp_half):
+        """amp_half: host (N, N, N/2+1) array of sqrt(P boxfactor)."""
+        N = self.N
+        padded = np.zeros((N, N, self.pitch), dtype=self.rdtype)
+        padded[:, :, :N // 2 + 1] = amp_half
+        self._amp_dense = self.upload_raw(padded)      # keep alive: the plan only borrows it
+        _lib.call("fb_set_amplitude_dense", self._plan, self._amp_dense.ptr)
+
+    def colour_noise(self, re, im):
+        out = self.empty(HALF)
+        _lib.call("fb_colour_noise", self._plan, re.ptr, im.ptr, out.ptr, self.stream)
+        return out
+
+    def colour_philox(self, seed, realisation):
+        out = self.empty(HALF)
+        _lib.call("fb_colour_philox", self._plan, int(seed) & (2 ** 64 - 1), int(realisation) & (2 ** 64 - 1),
+                  out.ptr, self.stream)
+        return out
+
+    # -- P(k) ---------------------------------------------------------------------
+    def set_bins(self, edges, thr=None, amb=()):
+        edges = np.ascontiguousarray(edges, dtype=np.float64)
+        key = (edges.tobytes(), None if thr is None else np.asarray(thr).tobytes(), tuple(amb))
+        if key == self._bins_key:
+            return
+        if thr is not None:
+            thr = np.ascontiguousarray(thr, dtype=np.int32)
+            ambv = np.ascontiguousarray(list(amb) + [0], dtype=np.int32)
+            _lib.call("fb_set_bins", self._plan, edges.ctypes.data_as(_lib.P_double), edges.size,
+                      thr.ctypes.data_as(_lib.P_i32), ambv.ctypes.data_as(_lib.P_i32), len(amb))
+        else:
+            _lib.call("fb_set_bins", self._plan, edges.ctypes.data_as(_lib.P_double), edges.size, None, None, 0)
+        self._bins_key = key
+        self._nbins = edges.size
+
+    def bin_power(self, spec):
+        """(count, sum |dk|^2, sum |dk|^4) per bin over the full grid."""
+        nb = self._nbins
+        cnt, s1, s2 = (np.zeros(nb) for _ in range(3))
+        _lib.call("fb_bin_power", self._plan, spec.ptr, 1 if spec.kind == HALF else 0,
+                  cnt.ctypes.data_as(_lib.P_double),
+                  s1.ctypes.data_as(_lib.P_double), s2.ctypes.data_as(_lib.P_double), self.stream)
+        return cnt, s1, s2
+
+    # -- k-space operators -----------------------------------------------------------
+    def apply_filter(self, spec, kind, params=(0, 0, 0, 0), table=None, inplace=False):
+        out = spec if inplace else self.empty(spec.kind)
+        prm = (ctypes.c_double * 4)(*[float(x) for x in params])
+        _lib.call("fb_apply_filter", self._plan, spec.ptr, out.ptr, 1 if spec.kind == HALF else 0, int(kind), prm,
+                  table.ptr if table is not None else None, self.stream)
+        out.invalidate()
+        return out
+
+    def velocity_k(self, spec, comp, fac):
+        out = self.empty(spec.kind)
+        _lib.call("fb_velocity_k", self._plan, spec.ptr, out.ptr, 1 if spec.kind == HALF else 0, int(comp),
+                  float(fac), self.stream)
+        return out
+
+    def potential_k(self, spec):
+        out = self.empty(spec.kind)
+        _lib.call("fb_potential_k", self._plan, spec.ptr, out.ptr, 1 if spec.kind == HALF else 0, self.stream)
+        return out
+
+    # -- real-space operators -----------------------------------------------------------
+    def lognormal(self, real):
+        out = self.empty(REAL)
+        mean = ctypes.c_double()
+        _lib.call("fb_lognormal", self._plan, real.ptr, out.ptr, ctypes.byref(mean), self.stream)
+        return out, mean.value
+
+    def redshift_space(self, delta, vz, Hz, sigma_nl=0.0, noise=None, seed=0):
+        out = self.empty(REAL)
+        _lib.call("fb_redshift_space", self._plan, delta.ptr, vz.ptr, noise.ptr if noise is not None else None,
+                  out.ptr, float(Hz), float(sigma_nl), int(seed) & (2 ** 64 - 1), self.stream)
+        return out
+
+    def sum_real(self, real, squared=False):
+        v = ctypes.c_double()
+        _lib.call("fb_sum_real", self._plan, real.ptr, 1 if squared else 0, ctypes.byref(v), self.stream)
+        return v.value
+
+    def sumsq_half(self, half):
+        v = ctypes.c_double()
+        _lib.call("fb_sumsq_half", self._plan, half.ptr, ctypes.byref(v), self.stream)
+        return v.value

@@ -1,0 +1,128 @@
+/*
+ * libfastbox_hip -- C ABI of the MI355X (gfx950) density-field hot path.
+ *
+ * The reference (philbull/FastBox, fastbox/box.py) has no FFI layer: its hot
+ * path is numpy calls inside the methods of `CosmoBox`.  This header is the
+ * boundary a ctypes/cffi binding of those methods binds instead; every entry
+ * point names the reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a
+ *     negative FB_ERR_* code, and fb_last_error() (thread local) says why;
+ *   - all field pointers are DEVICE pointers owned by the caller (hipMalloc,
+ *     a torch tensor's data_ptr(), ...).  `stream` is a hipStream_t (NULL =
+ *     default stream); calls are asynchronous unless stated otherwise;
+ *   - precision is fixed per plan: 4 = float / complex64, 8 = double /
+ *     complex128 (the reference is float64 throughout);
+ *   - layouts are C order with z fastest, like the reference's ndarrays:
+ *       real : T          [N][N][N]
+ *       full : complex<T> [N][N][N]
+ *       half : complex<T> [N][N][pitch], k_z = 0..N/2 stored, pitch = fb_half_pitch()
+ *     A half spectrum represents the Hermitian array fftn(real field).
+ *   - one plan per host thread at a time (thread compatible, not thread safe).
+ */
+#ifndef FASTBOX_HIP_H
+#define FASTBOX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FB_OK 0
+#define FB_ERR_INVALID -1      /* bad argument                        */
+#define FB_ERR_HIP -2          /* HIP runtime / launch failure        */
+#define FB_ERR_UNSUPPORTED -3  /* grid size not a power of two 16..2048 */
+#define FB_ERR_NOMEM -4
+#define FB_ERR_STATE -5        /* tables not set before use           */
+
+typedef struct fb_plan fb_plan;
+
+int fb_version(void);
+const char* fb_last_error(void);
+
+/* ---- plan: geometry of one CosmoBox (box.py:25-127) ---------------------------------- */
+/* axis2[3*N]: (m_i/L_a)**2; ksc[3*N]: m_i*(2 pi/L_a); kpar[N]: 2 pi m_i/Lz; zgrid[N]: self.z.
+ * They are computed by the host binding with the reference's numpy expressions
+ * (box.py:119-127, 254-256, 375, 79-88) so that |k| is bit-identical.            */
+int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int precision, int device,
+                   const double* axis2, const double* ksc, const double* kpar, const double* zgrid);
+int fb_plan_destroy(fb_plan* plan);
+int fb_half_pitch(const fb_plan* plan);          /* complex elements per (x,y) row of a half spectrum */
+int64_t fb_real_bytes(const fb_plan* plan);
+int64_t fb_half_bytes(const fb_plan* plan);
+int64_t fb_full_bytes(const fb_plan* plan);
+
+/* ---- 3-D FFTs (numpy.fft.fftn / ifftn, box.py:187,193,246,337,380,654,736) ------------- */
+/* in place on a full complex array; direction -1 = fftn, +1 = ifftn (scale applied: pass 1/N^3) */
+int fb_fft_c2c(fb_plan* plan, void* full_inout, int direction, double scale, void* stream);
+/* fftn of a real field -> half spectrum.  pre_exp != 0 transforms exp(field) (log-normal fusion) */
+int fb_fft_r2c(fb_plan* plan, const void* real_in, void* half_out, int pre_exp, void* stream);
+/* Re ifftn of the Hermitian array a half spectrum stands for; `half_inout` is destroyed */
+int fb_fft_c2r(fb_plan* plan, void* half_inout, void* real_out, double scale, void* stream);
+
+/* ---- Gaussian realisation (realise_density, box.py:161-187) --------------------------- */
+/* sqrt(nan_to_num(P(k)) * boxfactor): per integer shell n^2=i^2+j^2+l^2 (cubic boxes) ...   */
+int fb_set_amplitude_shells(fb_plan* plan, const double* amp, int64_t nshell);
+/* ... or per stored mode, a DEVICE array T[N][N][pitch] (any box shape)                    */
+int fb_set_amplitude_dense(fb_plan* plan, const void* amp_dev);
+/* parity mode: re, im are the reference's np.random.normal draws, T[N][N][N] on the device  */
+int fb_colour_noise(fb_plan* plan, const void* re, const void* im, void* half_out, void* stream);
+/* throughput mode: Philox4x32-10 keyed by seed, counter = (mode index, realisation)         */
+int fb_colour_philox(fb_plan* plan, uint64_t seed, uint64_t realisation, void* half_out, void* stream);
+
+/* ---- binned power spectrum (binned_power_spectrum, box.py:741-764) ------------------------- */
+/* edges[nbins] as in np.digitize(k, edges).  thr/amb describe, for cubic boxes, the bin as a
+ * step function of the integer shell (thr[b] = first n^2 with |k| >= edges[b]; amb = shells
+ * to decide with the exact fp64 |k|); pass thr = NULL to always use the exact expression.   */
+int fb_set_bins(fb_plan* plan, const double* edges, int nbins, const int32_t* thr, const int32_t* amb, int namb);
+/* spec: layout 1 = half spectrum (mirrored modes counted twice), 0 = full complex array.
+ * host outputs: count[nbins] (modes of the full grid per bin), sum[nbins] = sum |dk|^2,
+ * sumsq[nbins] = sum |dk|^4.  Synchronises the stream.                                       */
+int fb_bin_power(fb_plan* plan, const void* spec, int layout, double* count, double* sum, double* sumsq,
+                 void* stream);
+
+/* ---- transfer functions (apply_transfer_fn box.py:374-379, smooth_field :651-653) ---------- */
+#define FB_FILT_TABLE 0          /* table: real multiplier, same layout as the field */
+#define FB_FILT_BEAM_HIGHPASS 1  /* (1-exp(-.5(|kpar|/p0)^p2)) [p0>0] * exp(-.5(kperp/p1)^2) [p1>0] */
+#define FB_FILT_WEDGE 2          /* 0 where |kpar| < p0*kperp + p1, else 1 */
+#define FB_FILT_TOPHAT 3         /* 3(sin x - x cos x)/x^3, x = |k| p0 */
+/* out = nan_to_num(in * T(kperp, kpar)); layout 0 = full, 1 = half; in == out allowed */
+int fb_apply_filter(fb_plan* plan, const void* in, void* out, int layout, int kind, const double* params,
+                    const void* table_dev, void* stream);
+
+/* ---- velocity / potential (box.py:251-284, 347-348) ------------------------------------------ */
+int fb_velocity_k(fb_plan* plan, const void* dk, void* out, int layout, int component, double fac, void* stream);
+int fb_potential_k(fb_plan* plan, const void* dk, void* out, int layout, void* stream);
+
+/* ---- real-space operators ---------------------------------------------------------------------- */
+/* out = exp(in)/mean(exp(in)) - 1 (box.py:457-460); *mean_out receives mean(exp(in)). Synchronises. */
+int fb_lognormal(fb_plan* plan, const void* real_in, void* real_out, double* mean_out, void* stream);
+/* redshift_space_density (box.py:405-437). noise: T[N][N][N] standard normals in LOS order
+ * (parity) or NULL -> Philox(seed) when sigma_nl > 0.                                             */
+int fb_redshift_space(fb_plan* plan, const void* delta, const void* vz, const void* noise, void* out,
+                      double Hz, double sigma_nl, uint64_t seed, void* stream);
+/* sum(x) / sum(x^2) over a real field; sum |dk|^2 over the FULL grid from a half spectrum
+ * (test_parseval, box.py:944-946).  Synchronise.                                                    */
+int fb_sum_real(fb_plan* plan, const void* real, int squared, double* out, void* stream);
+int fb_sumsq_half(fb_plan* plan, const void* half, double* out, void* stream);
+
+/* ---- layout conversion -------------------------------------------------------------------------- */
+int fb_expand_half(fb_plan* plan, const void* half, void* full, void* stream);  /* Hermitian extension */
+int fb_crop_full(fb_plan* plan, const void* full, void* half, void* stream);    /* keep k_z <= N/2      */
+
+/* ---- device memory helpers for bindings without their own allocator ---------------------------- */
+int fb_malloc(void** dev_ptr, size_t bytes);
+int fb_free(void* dev_ptr);
+int fb_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int fb_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int fb_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+int fb_stream_sync(void* stream);
+int fb_device_count(int* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

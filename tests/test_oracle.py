@@ -1,0 +1,109 @@
+"""CPU: pins the numpy restatement (oracle/box_oracle.py) against the golden vectors that
+oracle/make_golden.py captured from the reference itself (fastbox/box.py run here)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import box_oracle as bo
+from oracle import standin
+
+CASES_ALL = ["n16_cube", "n16_cuboid", "n32_l1000", "n64_l1000"]
+CASES_PK = ["n64_l100", "n64_l4000", "n128_l1000"]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _scale(g):
+    bs = g["box_scale"]
+    return tuple(float(b) for b in bs) if bs.size == 3 else float(bs[0])
+
+
+def _realise(g):
+    """Regenerate the case from its seed with the oracle."""
+    N = int(g["N"])
+    geo = bo.box_geometry(_scale(g), N)
+    a = 1. / (1. + float(g["redshift"]))
+    cosmo = standin.cosmology()
+    rng = np.random.RandomState(int(g["seed"]))
+    re, im = bo.draw_noise(N, rng)
+    dx, dk = bo.realise_density(geo, standin.pk_fn(cosmo, a), re, im)
+    return geo, cosmo, a, rng, dx, dk
+
+
+def _same(a, b):
+    """Bit-for-bit (NaNs in the same places)."""
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+@pytest.mark.parametrize("name", CASES_ALL + CASES_PK)
+def test_geometry_density_pk(golden_dir, name):
+    g = _load(golden_dir, name)
+    geo, cosmo, a, rng, dx, dk = _realise(g)
+    s = int(g["stride"])
+    for key in ("Lx", "Ly", "Lz", "boxfactor", "kmin", "kmax"):
+        assert geo[key] == float(g[key]), key
+    assert _same(geo["x"], g["x"]) and _same(geo["z"], g["z"])
+    assert _same(dx[::s, ::s, ::s], g["delta_x"])
+    assert _same(dk[::s, ::s, ::s], g["delta_k"])
+    assert np.sum(dx) == float(g["delta_x_sum"])
+    for nb in (20, 50):
+        kc, pk, err = bo.binned_power_spectrum(geo, dk, nbins=nb)
+        assert _same(kc, g["pk%d_k" % nb]) and _same(pk, g["pk%d_p" % nb]) and _same(err, g["pk%d_e" % nb])
+    kc, pk, err = bo.binned_power_spectrum(geo, dk, kbins=g["kbins"])
+    assert _same(kc, g["pkkb_k"]) and _same(pk, g["pkkb_p"]) and _same(err, g["pkkb_e"])
+    assert _same(np.array(bo.parseval(dx, dk)), g["parseval"])
+    Hz = standin.hubble(cosmo, a)
+    assert _same(bo.freq_array(geo, a, 1420.405752, Hz), g["freq_array"])
+
+
+@pytest.mark.parametrize("name", CASES_ALL)
+def test_derived_fields(golden_dir, name):
+    g = _load(golden_dir, name)
+    geo, cosmo, a, rng, dx, dk = _realise(g)
+    s = int(g["stride"])
+    p = lambda x: x[::s, ::s, ::s]
+    ln = bo.lognormal(dx)
+    assert _same(p(ln), g["lognormal"])
+    kc, pk, err = bo.binned_power_spectrum(geo, np.fft.fftn(ln))
+    assert _same(pk, g["pkln_p"]) and _same(err, g["pkln_e"])
+    assert _same(p(bo.apply_transfer_fn(geo, dk, standin.beam_highpass)), g["tf_beam"])
+    assert _same(p(bo.apply_transfer_fn(geo, dk, standin.highpass3)), g["tf_hp3"])
+    assert _same(p(bo.smooth_field(geo, dk, 8.0, cosmo['h'])), g["smooth8"])
+    vel = bo.realise_velocity(geo, dk, standin.velocity_fac(cosmo, a))
+    for c in range(3):
+        assert _same(p(vel[c]), g["vel%d_k" % c])
+    vz = np.fft.ifftn(vel[2]).real
+    assert _same(p(vz), g["vel_z"])
+    assert _same(p(bo.realise_potential(geo, dk)), g["phi_k"])
+    Hz = standin.hubble(cosmo, 1. / (1. + float(g["redshift"])))
+    rsd0 = bo.redshift_space_density(geo, dx, vz, Hz, 0.)
+    assert _same(p(rsd0), g["rsd0"])
+    assert _same(p(bo.redshift_space_density(geo, dx, vz, Hz, 200., rng)), g["rsd200"])
+    kc, pk, err = bo.binned_power_spectrum(geo, np.fft.fftn(rsd0))
+    assert _same(pk, g["pkrsd_p"])
+
+
+def test_oracle_against_live_reference():
+    """When the reference is on this machine, compare directly on a fresh seed."""
+    from oracle import ref_loader
+    if not ref_loader.reference_available():
+        pytest.skip("reference sources not present (GPU box)")
+    ref = ref_loader.load_reference_box()
+    np.random.seed(5)
+    box = ref.CosmoBox(cosmo=standin.DEFAULT_COSMO, box_scale=(3e2, 3e2, 3e2), nsamp=24, realise_now=False)
+    box.realise_density()
+    geo = bo.box_geometry((3e2, 3e2, 3e2), 24)
+    rng = np.random.RandomState(5)
+    re, im = bo.draw_noise(24, rng)
+    dx, dk = bo.realise_density(geo, standin.pk_fn(standin.cosmology(), 1.0), re, im)
+    assert _same(dx, box.delta_x) and _same(dk, box.delta_k)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref_pk = box.binned_power_spectrum(nbins=30)
+    ora_pk = bo.binned_power_spectrum(geo, dk, nbins=30)
+    for a, b in zip(ref_pk, ora_pk):
+        assert _same(a, b)
