@@ -366,8 +366,10 @@ class CosmoBox(object):
         cnt, s1, s2 = self.engine.bin_power(spec)
         with np.errstate(all="ignore"):
             vals = s1 / (cnt * self.boxfactor)
-            var = s2 / (cnt * self.boxfactor ** 2) - vals ** 2
-            stddev = np.sqrt(np.maximum(var, 0.)) / np.sqrt(cnt)
+            # population variance from the raw sums; this form is exactly 0 for a bin whose
+            # modes all carry the same |delta_k|^2 (a mirrored pair), as np.std gives
+            var = (s2 - s1 * s1 / cnt) / cnt
+            stddev = np.sqrt(np.maximum(var, 0.)) / self.boxfactor / np.sqrt(cnt)
         return np.array(cent[1:]), np.array(vals[1:]), np.array(stddev[1:])
 
     def sigmaR(self, R):

@@ -44,12 +44,16 @@ def _field_close(a, b, tol):
 
 
 def _pk_close(got, want, tol):
-    for a, b in zip(got, want):
+    """got/want = (pk,) or (pk, stddev).  pk: relative.  stddev: relative, with an absolute
+    floor of tol * pk (the reference's std is exactly 0 for single-valued bins)."""
+    pk_ref = np.asarray(want[0])
+    for n, (a, b) in enumerate(zip(got, want)):
         a, b = np.asarray(a), np.asarray(b)
         if not np.array_equal(np.isnan(a), np.isnan(b)):
             return False
         m = ~np.isnan(b)
-        if not np.allclose(a[m], b[m], rtol=tol, atol=0):
+        atol = 0 if n == 0 else tol * np.abs(pk_ref[m])
+        if not np.all(np.abs(a[m] - b[m]) <= tol * np.abs(b[m]) + atol):
             return False
     return True
 
