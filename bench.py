@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""
+Headline benchmark: 512^3 box realisations per second (BASELINE.json `metric`,
+configs[1]: "512^3 Gaussian box + log-normal transform + P(k) estimate on 1x MI355X").
+
+One step = one pass of the hot path through the public API, inputs resident in HBM:
+
+    dx = box.realise_density()                       # Threefry noise, sqrt(P) colouring, c2r 3-D FFT
+    pending = box.binned_power_spectrum(delta_x=box.lognormal(dx), nbins=20, wait=False)
+
+The K pending spectra are resolved (2*20+1 doubles each) inside the timed region, after the
+last step has been queued; fields never leave HBM.  With --gpus N every rank runs
+independent realisations of the same box (Monte-Carlo replicas, no data-path collective;
+"scaling": "weak"); `value` is the whole-job rate.
+
+Prints ONE JSON line (see README / DESIGN.md for the fields).  `roofline` is for the
+dominant kernel class (the strided x/y FFT passes), timed live with HIP events on the
+launch stream; `cpu_baseline` is the numpy oracle (the reference's algorithm) on one core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nsamp", type=int, default=512)
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--nbins", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-nsamp", type=int, default=256)
+    return ap.parse_args()
+
+
+def cpu_baseline(nsamp_bench, nsamp_cpu, nbins):
+    """The reference algorithm (oracle restatement: numpy pocketfft, 1 thread) on the host,
+    on a bounded sample, scaled to the metric's unit by voxel count."""
+    import numpy as np
+    from oracle import box_oracle as bo
+    from oracle import standin
+    geo = bo.box_geometry(1e3, nsamp_cpu)
+    cosmo = standin.cosmology()
+    rng = np.random.RandomState(1)
+    t0 = time.time()
+    re, im = bo.draw_noise(nsamp_cpu, rng)
+    dx, dk = bo.realise_density(geo, standin.pk_fn(cosmo, 1.0), re, im)
+    ln = bo.lognormal(dx)
+    bo.binned_power_spectrum(geo, np.fft.fftn(ln), nbins=nbins)
+    dt = time.time() - t0
+    scale = (nsamp_bench / float(nsamp_cpu)) ** 3
+    return {"value": 1.0 / (dt * scale), "unit": "boxes/s", "cores": 1, "kind": "port",
+            "sample": "one %d^3 realise_density + lognormal + binned_power_spectrum with the numpy oracle "
+                      "(%.1f s, 1 thread), scaled by voxel count x%.0f to %d^3"
+                      % (nsamp_cpu, dt, scale, nsamp_bench)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch                                  # first: pins one HIP runtime for the process
+    import torch.distributed as dist
+    import numpy as np
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from fastbox_amd import CosmoBox, default_cosmo
+
+    N = args.nsamp
+    box = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, redshift=0., realise_now=False,
+                   precision=args.precision, rng="device", seed=1000 + rank, device=local_rank)
+    eng = box.engine
+
+    def step():
+        dx = box.realise_density()
+        return box.binned_power_spectrum(delta_x=box.lognormal(dx), nbins=args.nbins, wait=False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step().result()
+    fence()
+    eng.profile_start()
+    t0 = time.perf_counter()
+    acc = np.zeros(args.nbins - 1)
+    pending = [step() for _ in range(args.steps)]
+    for pnd in pending:
+        kc, pk, err = pnd.result()
+        acc += np.nan_to_num(pk)
+    prof = eng.profile_stop()                    # synchronises the launch stream
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # roofline of the dominant kernel class: strided FFT pass over a half spectrum reads and
+        # writes N*N*(N/2+1) complex values once each (DESIGN.md "Algorithmic bytes")
+        s = 4 if args.precision == "f32" else 8
+        ms, launches = prof["fft_strided"]
+        alg_bytes = 2.0 * N * N * (N // 2 + 1) * 2 * s
+        achieved = alg_bytes / (ms / max(launches, 1) * 1e-3) / 1e9 if ms > 0 else None
+        total_ms = sum(v[0] for v in prof.values())
+        line = {
+            "metric": "%d^3 box realisations/sec (gen + log-normal + P(k))" % N,
+            "value": world * args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "%d^3 Gaussian box (device Threefry noise, stand-in EH P(k), L=1000 Mpc) + "
+                                   "log-normal transform + binned P(k), nbins=%d" % (N, args.nbins),
+                       "nsamp": N, "parallelism": "replicas x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_fft_strided (x/y FFT pass, half spectrum)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                         "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches},
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
+            "kernel_ms_total_per_step": round(total_ms / args.steps, 4),
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N, args.cpu_nsamp, args.nbins)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,7 +35,7 @@ SIGNATURES = {
     "fb_set_amplitude_shells": (c_int, [c_void_p, P_double, c_i64]),
     "fb_set_amplitude_dense": (c_int, [c_void_p, c_void_p]),
     "fb_colour_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "fb_colour_philox": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p]),
+    "fb_colour_device": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p]),
     "fb_set_bins": (c_int, [c_void_p, P_double, c_int, P_i32, P_i32, c_int]),
     "fb_bin_power": (c_int, [c_void_p, c_void_p, c_int, P_double, P_double, P_double, c_void_p]),
     "fb_apply_filter": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, P_double, c_void_p, c_void_p]),
@@ -48,6 +48,11 @@ SIGNATURES = {
     "fb_sumsq_half": (c_int, [c_void_p, c_void_p, P_double, c_void_p]),
     "fb_expand_half": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_crop_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fb_realise_density_device": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p, c_void_p]),
+    "fb_power_spectrum_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "fb_bin_counts": (c_int, [c_void_p, P_double]),
+    "fb_profile_start": (c_int, [c_void_p]),
+    "fb_profile_stop": (c_int, [c_void_p, c_void_p, P_double, ctypes.POINTER(c_i64), c_int]),
     "fb_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size_t]),
     "fb_free": (c_int, [c_void_p]),
     "fb_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

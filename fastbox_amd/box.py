@@ -8,8 +8,9 @@ reference; fields are returned as ``DeviceArray`` objects that stay in HBM and
 turn into float64 / complex128 ndarrays when numpy touches them.  Additive,
 reference-preserving keyword arguments: ``precision`` ('f32' storage with fp64
 bin sums, or 'f64'), ``rng`` ('numpy' = the reference's legacy global stream,
-drawn on the host and uploaded -- same seed, same field; 'philox' = on-device
-counter-based RNG for throughput), ``seed``, ``device``, ``stream``.
+drawn on the host and uploaded -- same seed, same field; 'device' = on-device
+counter-based Threefry4x32-20 RNG for throughput, reproducible on the host with
+``fastbox_amd.rng``), ``seed``, ``device``, ``stream``.
 
 No CPU fallback exists: without the HIP library or a GPU every compute method
 raises.
@@ -37,6 +38,63 @@ try:
     from scipy.integrate import simpson as _simpson
 except Exception:                           # pragma: no cover
     from scipy.integrate import simps as _simpson
+
+
+def _finish_bins(cnt, s1, s2, boxfactor):
+    """(mean, std/sqrt(n)) per bin from (count, sum |dk|^2, sum |dk|^4), bin 0 dropped
+    (box.py:761-768).  The variance form is exactly 0 for a bin whose modes all carry the
+    same |delta_k|^2 (a mirrored pair), as np.std gives; empty bins are NaN."""
+    with np.errstate(all="ignore"):
+        vals = s1 / (cnt * boxfactor)
+        var = (s2 - s1 * s1 / cnt) / cnt
+        stddev = np.sqrt(np.maximum(var, 0.)) / boxfactor / np.sqrt(cnt)
+    return np.array(vals[1:]), np.array(stddev[1:])
+
+
+class _Ready(object):
+    def __init__(self, out):
+        self._out = out
+
+    def result(self):
+        return self._out
+
+
+class PendingSpectrum(object):
+    """Handle on a power spectrum whose bin sums are still being computed on the device."""
+
+    def __init__(self, engine, res, nbins, kc, boxfactor, ln_voxels, keepalive):
+        self._eng, self._res, self._nb, self._kc, self._bf = engine, res, nbins, kc, boxfactor
+        self._lnv, self._keep, self._out = ln_voxels, keepalive, None
+        self._cnt = engine.bin_counts()
+
+    def result(self):
+        if self._out is None:
+            s1, s2, esum = self._eng.fetch_results(self._res, self._nb)
+            if self._lnv:                      # transform of exp(d): rescale to exp(d)/mean - 1
+                mean = esum / self._lnv
+                s1, s2 = s1 / mean ** 2, s2 / mean ** 4
+            self._out = (self._kc,) + _finish_bins(self._cnt, s1, s2, self._bf)
+            self._res = self._keep = None
+        return self._out
+
+
+class LognormalField(DeviceArray):
+    """exp(d)/<exp(d)> - 1 of a device field, materialised on first read."""
+
+    def __init__(self, engine, source):
+        DeviceArray.__init__(self, engine, REAL, None)
+        self.source = source
+
+    @property
+    def materialised(self):
+        return self._buf is not None
+
+    @property
+    def ptr(self):
+        if self._buf is None:
+            out, _ = self.engine.lognormal(self.source)
+            self._buf = out._buf
+        return self._buf.ptr
 
 
 class CosmoBox(object):
@@ -68,8 +126,10 @@ class CosmoBox(object):
         self.kmin = 2. * np.pi / np.max([self.Lx, self.Ly, self.Lz])          # box.py:100
         self.kmax = 2. * np.pi * np.sqrt(3.) * self.N / np.min([self.Lx, self.Ly, self.Lz])
 
-        if rng not in ("numpy", "philox"):
-            raise ValueError("rng must be 'numpy' or 'philox'")
+        if rng in ("threefry", "philox"):          # historical spellings of the device generator
+            rng = "device"
+        if rng not in ("numpy", "device"):
+            raise ValueError("rng must be 'numpy' or 'device'")
         self.rng, self.seed, self._realisation = rng, int(seed), 0
         self._cubic = (self.Lx == self.Ly == self.Lz)
         self._grids = None
@@ -199,10 +259,12 @@ class CosmoBox(object):
             im = eng.upload(np.random.normal(0.0, 1.0, (N, N, N)), REAL)
             half = eng.colour_noise(re, im)
             del re, im
+            delta_x = eng.fft_c2r(half, destroy=True)
         else:
-            half = eng.colour_philox(self.seed, self._realisation)
+            # generator fused into the first inverse FFT pass (no coloured spectrum round trip)
+            delta_x = eng.realise_fused(self.seed, self._realisation)
+            self.last_realisation = self._realisation
             self._realisation += 1
-        delta_x = eng.fft_c2r(half, destroy=True)
         if inplace:
             if redshift != self.redshift:
                 print("Warning: Storing density field into self.delta_x with a "
@@ -320,9 +382,10 @@ class CosmoBox(object):
 
     # ------------------------------------------------------------------- log-normal
     def lognormal(self, delta_x):
-        """exp(delta)/<exp(delta)> - 1 (box.py:441-460)."""
-        out, _ = self.engine.lognormal(self._as_real(delta_x))
-        return out
+        """exp(delta)/<exp(delta)> - 1 (box.py:441-460).  Returned lazily: the field is
+        computed when it is first read, and ``binned_power_spectrum(delta_x=...)`` of it
+        fuses the exp() into the first FFT pass instead of materialising it."""
+        return LognormalField(self.engine, self._as_real(delta_x))
 
     # ----------------------------------------------------------------- power spectrum
     def _shell_thresholds(self, bins):
@@ -340,37 +403,45 @@ class CosmoBox(object):
         thr = np.searchsorted(hi, np.arange(1, bins.size + 1), side="left")
         return thr.astype(np.int32), tuple(int(a) for a in amb)
 
-    def binned_power_spectrum(self, delta_x=None, delta_k=None, nbins=20, kbins=None):
+    def binned_power_spectrum(self, delta_x=None, delta_k=None, nbins=20, kbins=None, wait=True):
         """Shell-averaged power spectrum of the realisation (box.py:696-768): bin centres,
         mean of |delta_k|^2/boxfactor and std/sqrt(n) per bin; bin 0 is dropped and empty
-        bins are NaN, as in the reference."""
+        bins are NaN, as in the reference.  ``wait=False`` (additive) returns a
+        ``PendingSpectrum`` at once; its ``result()`` gives the same triple later, so that
+        many realisations can be queued without a host round trip each."""
         if delta_x is not None and delta_k is not None:
             raise ValueError("delta_x and delta_k specified; can only specify one")
-        if delta_x is not None:
-            spec = self.engine.fft_r2c(self._as_real(delta_x))
-        elif delta_k is None:
-            spec = self.delta_k
-        else:
-            spec = self._as_spectrum(delta_k)
         if kbins is not None:
             bins = np.asarray(kbins, dtype=np.float64)
         else:
             bins = np.logspace(np.log10(self.kmin), np.log10(self.kmax), nbins)   # box.py:749
         _bins = [0.0] + list(bins)
         cent = [0.5 * (_bins[j + 1] + _bins[j]) for j in range(bins.size)]
+        kc = np.array(cent[1:])
 
         thr, amb = (None, ())
         if self._cubic and np.all(np.diff(bins) >= 0):
             thr, amb = self._shell_thresholds(bins)
-        self.engine.set_bins(bins, thr, amb)
-        cnt, s1, s2 = self.engine.bin_power(spec)
-        with np.errstate(all="ignore"):
-            vals = s1 / (cnt * self.boxfactor)
-            # population variance from the raw sums; this form is exactly 0 for a bin whose
-            # modes all carry the same |delta_k|^2 (a mirrored pair), as np.std gives
-            var = (s2 - s1 * s1 / cnt) / cnt
-            stddev = np.sqrt(np.maximum(var, 0.)) / self.boxfactor / np.sqrt(cnt)
-        return np.array(cent[1:]), np.array(vals[1:]), np.array(stddev[1:])
+        eng = self.engine
+        eng.set_bins(bins, thr, amb)
+
+        if delta_x is not None and thr is not None:
+            # fused path (cubic boxes): r2c with the binning inside the last pass
+            ln = isinstance(delta_x, LognormalField) and not delta_x.materialised and bins[0] > 0.
+            src = delta_x.source if ln else self._as_real(delta_x)
+            res, _ = eng.power_fused(src, pre_exp=ln)
+            pending = PendingSpectrum(eng, res, bins.size, kc, self.boxfactor, self.N ** 3 if ln else None, src)
+            return pending if not wait else pending.result()
+
+        if delta_x is not None:
+            spec = eng.fft_r2c(self._as_real(delta_x))
+        elif delta_k is None:
+            spec = self.delta_k
+        else:
+            spec = self._as_spectrum(delta_k)
+        cnt, s1, s2 = eng.bin_power(spec)
+        out = (kc,) + _finish_bins(cnt, s1, s2, self.boxfactor)
+        return out if wait else _Ready(out)
 
     def sigmaR(self, R):
         """RMS of the field smoothed with a top-hat of R Mpc/h, from the binned power

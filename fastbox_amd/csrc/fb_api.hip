@@ -85,7 +85,7 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
 int fb_plan_destroy(fb_plan* p) {
     if (!p) return FB_OK;
     void* ptrs[] = {p->tw, p->axis2, p->ksc, p->kpar, p->zgrid, p->amp_shell, p->bins, p->thr, p->counts,
-                    p->partials, p->scratch};
+                    p->partials, p->scratch, p->bin_partials, p->exp_partials};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     delete p;
     return FB_OK;
@@ -131,11 +131,11 @@ int fb_colour_noise(fb_plan* p, const void* re, const void* im, void* out, void*
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_colour_noise_f32(p, re, im, out, s), fbi_colour_noise_f64(p, re, im, out, s));
 }
-int fb_colour_philox(fb_plan* p, uint64_t seed, uint64_t realisation, void* out, void* stream) {
+int fb_colour_device(fb_plan* p, uint64_t seed, uint64_t realisation, void* out, void* stream) {
     FB_REQUIRE(p && out, "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    return FB_DISPATCH(p, fbi_colour_philox_f32(p, seed, realisation, out, s),
-                       fbi_colour_philox_f64(p, seed, realisation, out, s));
+    return FB_DISPATCH(p, fbi_colour_device_f32(p, seed, realisation, out, s),
+                       fbi_colour_device_f64(p, seed, realisation, out, s));
 }
 
 int fb_set_bins(fb_plan* p, const double* edges, int nbins, const int32_t* thr, const int32_t* amb, int namb) {
@@ -228,6 +228,52 @@ int fb_crop_full(fb_plan* p, const void* full, void* half, void* stream) {
     FB_REQUIRE(p && half && full, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_crop_full_f32(p, full, half, s), fbi_crop_full_f64(p, full, half, s));
+}
+
+int fb_realise_density_device(fb_plan* p, uint64_t seed, uint64_t realisation, void* work_half, void* real_out,
+                              void* stream) {
+    FB_REQUIRE(p && work_half && real_out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const double scale = 1.0 / ((double)p->N * p->N * p->N);
+    return FB_DISPATCH(p, fbi_realise_fused_f32(p, seed, realisation, work_half, real_out, scale, s),
+                       fbi_realise_fused_f64(p, seed, realisation, work_half, real_out, scale, s));
+}
+int fb_power_spectrum_device(fb_plan* p, const void* real_in, void* work_half, int pre_exp, int keep_spectrum,
+                             double* results_dev, void* stream) {
+    FB_REQUIRE(p && real_in && work_half && results_dev, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_power_fused_f32(p, real_in, work_half, pre_exp, keep_spectrum, results_dev, s),
+                       fbi_power_fused_f64(p, real_in, work_half, pre_exp, keep_spectrum, results_dev, s));
+}
+int fb_bin_counts(fb_plan* p, double* count) {
+    FB_REQUIRE(p && count, "null pointer");
+    FB_REQUIRE(p->nbins > 0, "bin edges not set");
+    for (int q = 0; q < p->nbins; ++q) count[q] = p->counts_host[q];
+    return FB_OK;
+}
+
+int fb_profile_start(fb_plan* p) {
+    FB_REQUIRE(p, "null pointer");
+    p->prof_used = 0;
+    p->prof_cat.clear();
+    p->prof_on = true;
+    return FB_OK;
+}
+int fb_profile_stop(fb_plan* p, void* stream, double* ms, int64_t* launches, int ncat) {
+    FB_REQUIRE(p && ms && launches, "null pointer");
+    FB_REQUIRE(ncat >= FBK_NCAT, "ncat must be >= FB_PROF_NCAT");
+    p->prof_on = false;
+    FB_HIP(hipStreamSynchronize((hipStream_t)stream));
+    for (int q = 0; q < ncat; ++q) { ms[q] = 0.0; launches[q] = 0; }
+    for (size_t i = 0; i + 1 < p->prof_used; i += 2) {
+        float t = 0.f;
+        FB_HIP(hipEventElapsedTime(&t, p->prof_ev[i], p->prof_ev[i + 1]));
+        const int c = p->prof_cat[i / 2];
+        ms[c] += (double)t;
+        launches[c] += 1;
+    }
+    p->prof_used = 0;
+    return FB_OK;
 }
 
 int fb_malloc(void** dev_ptr, size_t bytes) {

@@ -7,6 +7,7 @@
 //   full  : cx<T>  [N][N][N]
 #pragma once
 #include "fb_fft.h"
+#include "fb_rng.h"
 
 namespace fb {
 
@@ -80,44 +81,27 @@ __global__ void k_colour_noise(const T* __restrict__ re, const T* __restrict__ i
     out[((long long)i * N + j) * g.NZP + l] = cx<T>{A * (re[a] + re[b]), A * (im[a] - im[b])};
 }
 
-// ---- Gaussian field, throughput mode (counter-based RNG) ---------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
-}
-template <typename T> __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, T& g0, T& g1) {
-    const T u1 = ((T)a + (T)0.5) * (T)2.3283064365386963e-10;
-    const T u2 = ((T)b + (T)0.5) * (T)2.3283064365386963e-10;
-    const T r = sqrt((T)-2 * log(u1));
-    T s, c;
-    fb_sincospi((T)2 * u2, &s, &c);
-    g0 = r * c; g1 = r * s;
-}
+// ---- Gaussian field, throughput mode (counter-based RNG, fb_rng.h) ------------------------------
 // Statistically identical to box.py:174-187 without the mirrored draw: a stored mode
-// gets A (g1 + i g2)/sqrt(2); on the self-mirrored planes k_z = 0, N/2 it gets
-// A (g1 + i g2) and the c2r pass's Hermitian projection halves the variance.
+// gets A (g0 + i g1)/sqrt(2); on the self-mirrored planes k_z = 0, N/2 it gets
+// A (g0 + i g1) and the c2r pass's Hermitian projection halves the variance.
 template <typename T>
-__global__ void k_colour_philox(cx<T>* __restrict__ out, AmpSrc<T> amp, KGeom g,
-                                uint32_t seed_lo, uint32_t seed_hi, uint32_t real_lo, uint32_t real_hi) {
+__device__ __forceinline__ T plane_factor(int l, int N) {
+    return (l == 0 || l == (N >> 1)) ? (T)1 : (T)0.70710678118654752440;
+}
+template <typename T>
+__global__ void k_colour_device(cx<T>* __restrict__ out, AmpSrc<T> amp, KGeom g, RngKey key) {
     const int N = g.N;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, i = blockIdx.z;
     if (l >= g.NZV) return;
-    const unsigned long long idx = ((unsigned long long)i * N + j) * g.NZV + l;
-    uint32_t o[4];
-    philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), real_lo, real_hi, seed_lo, seed_hi, o);
-    T g0, g1;
-    box_muller<T>(o[0], o[1], g0, g1);
-    T A = amp_at(amp, g, i, j, l);
-    if (l != 0 && l != (N >> 1)) A *= (T)0.70710678118654752440;
-    out[((long long)i * N + j) * g.NZP + l] = cx<T>{A * g0, A * g1};
+    const int gi = i & ((N >> 1) - 1);
+    const unsigned long long idx = ((unsigned long long)gi * N + j) * g.NZV + l;
+    T a0, a1, b0, b1;
+    mode_noise_pair<T>(idx, 0u, key, a0, a1, b0, b1);
+    const T A = amp_at(amp, g, i, j, l) * plane_factor<T>(l, N);
+    const bool hi = i >= (N >> 1);
+    out[((long long)i * N + j) * g.NZP + l] = cx<T>{A * (hi ? b0 : a0), A * (hi ? b1 : a1)};
 }
 
 // ---- shell binning of |delta_k|^2 --------------------------------------------------------------
@@ -384,7 +368,7 @@ __global__ void k_crop_full(const cx<T>* __restrict__ full, cx<T>* __restrict__ 
 template <typename T>
 __global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise,
                       T* __restrict__ out, const double* __restrict__ zgrid, int N, double Hz, double sigma_nl,
-                      uint32_t seed_lo, uint32_t seed_hi) {
+                      RngKey rkey) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* key = reinterpret_cast<double*>(smem);   // [N]
     double* val = key + N;                            // [N]
@@ -400,10 +384,10 @@ __global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, con
             double n;
             if (noise) n = (double)noise[los * N + m];
             else {
-                uint32_t o[4];
                 const unsigned long long idx = (unsigned long long)los * N + m;
-                philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), 0x52534421u, 0u, seed_lo, seed_hi, o);
-                double g0, g1; box_muller<double>(o[0], o[1], g0, g1); n = g0;
+                double g0, g1, g2, g3;
+                mode_noise_pair<double>(idx, 1u, rkey, g0, g1, g2, g3);
+                n = g0;
             }
             vel = vel + sigma_nl * n;
         }

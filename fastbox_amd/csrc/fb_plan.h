@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #define FB_OK 0
 #define FB_ERR_INVALID -1
@@ -43,6 +44,38 @@ struct fb_plan {
     double* partials = nullptr;  // [prow][3*FB_MAX_BINS] per-workgroup partial sums
     int prow = 0;
     double* scratch = nullptr;   // small reduction scratch [FB_SCRATCH]
+    double* bin_partials = nullptr;   // fused binning: [workgroups][2*nbins]
+    size_t bin_partials_cap = 0;
+    long long bin_rows = 0;
+    double* exp_partials = nullptr;   // r2c with exp(): [workgroups]
+    size_t exp_partials_cap = 0;
+    long long exp_rows = 0;
+
+    // per-kernel HIP-event timing (fb_profile_start / fb_profile_stop)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;   // pairs
+    std::vector<int> prof_cat;
+    size_t prof_used = 0;
+};
+
+// kernel classes reported by fb_profile_stop (keep in sync with FB_PROF_* in fastbox_hip.h)
+enum { FBK_FFT_STRIDED = 0, FBK_FFT_CONTIG, FBK_COLOUR, FBK_BIN, FBK_FILTER, FBK_VELPOT, FBK_REALOP, FBK_RSD,
+       FBK_LAYOUT, FBK_FFT_GEN, FBK_FFT_BIN, FBK_NCAT };
+
+// RAII: records an event pair around one launch while profiling is on
+struct FbProfScope {
+    fb_plan* p; hipStream_t s; size_t slot; bool on;
+    FbProfScope(fb_plan* plan, int cat, hipStream_t stream) : p(plan), s(stream), slot(0), on(plan->prof_on) {
+        if (!on) return;
+        if (p->prof_used + 2 > p->prof_ev.size()) {
+            for (int q = 0; q < 64; ++q) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+                                           p->prof_ev.push_back(e); }
+        }
+        slot = p->prof_used; p->prof_used += 2;
+        p->prof_cat.resize(p->prof_used / 2); p->prof_cat[slot / 2] = cat;
+        (void)hipEventRecord(p->prof_ev[slot], s);
+    }
+    ~FbProfScope() { if (on) (void)hipEventRecord(p->prof_ev[slot + 1], s); }
 };
 
 #define FB_MAX_BINS 256
@@ -60,7 +93,7 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_fft_c2r_##sfx(fb_plan* p, void* half_inout, void* real_out, double scale, hipStream_t s); \
     int fbi_set_amp_shells_##sfx(fb_plan* p, const double* amp, int64_t n); \
     int fbi_colour_noise_##sfx(fb_plan* p, const void* re, const void* im, void* out, hipStream_t s); \
-    int fbi_colour_philox_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* out, hipStream_t s); \
+    int fbi_colour_device_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* out, hipStream_t s); \
     int fbi_bin_power_##sfx(fb_plan* p, const void* spec, int layout, double* sums_dev, hipStream_t s); \
     int fbi_apply_filter_##sfx(fb_plan* p, const void* in, void* out, int layout, int kind, const double* prm, \
                                const void* table, hipStream_t s); \
@@ -72,7 +105,11 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_sum_real_##sfx(fb_plan* p, const void* x, int squared, double* out, hipStream_t s); \
     int fbi_sumsq_half_##sfx(fb_plan* p, const void* h, double* out, hipStream_t s); \
     int fbi_expand_half_##sfx(fb_plan* p, const void* h, void* f, hipStream_t s); \
-    int fbi_crop_full_##sfx(fb_plan* p, const void* f, void* h, hipStream_t s);
+    int fbi_crop_full_##sfx(fb_plan* p, const void* f, void* h, hipStream_t s); \
+    int fbi_realise_fused_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* work_half, void* real_out, \
+                                double scale, hipStream_t s); \
+    int fbi_power_fused_##sfx(fb_plan* p, const void* real_in, void* work_half, int pre_exp, int store, \
+                              double* results, hipStream_t s);
 FB_DECL(f32)
 FB_DECL(f64)
 int fbi_bin_count(fb_plan* p, hipStream_t s);

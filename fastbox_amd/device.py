@@ -257,9 +257,9 @@ class Engine(object):
         _lib.call("fb_colour_noise", self._plan, re.ptr, im.ptr, out.ptr, self.stream)
         return out
 
-    def colour_philox(self, seed, realisation):
+    def colour_device(self, seed, realisation):
         out = self.empty(HALF)
-        _lib.call("fb_colour_philox", self._plan, int(seed) & (2 ** 64 - 1), int(realisation) & (2 ** 64 - 1),
+        _lib.call("fb_colour_device", self._plan, int(seed) & (2 ** 64 - 1), int(realisation) & (2 ** 64 - 1),
                   out.ptr, self.stream)
         return out
 
@@ -320,6 +320,53 @@ class Engine(object):
         _lib.call("fb_redshift_space", self._plan, delta.ptr, vz.ptr, noise.ptr if noise is not None else None,
                   out.ptr, float(Hz), float(sigma_nl), int(seed) & (2 ** 64 - 1), self.stream)
         return out
+
+    # -- fused throughput path -------------------------------------------------------------
+    def _scratch_half(self):
+        if getattr(self, "_work_half", None) is None:
+            self._work_half = self.empty(HALF)
+        return self._work_half
+
+    def realise_fused(self, seed, realisation):
+        """Device-RNG Gaussian field; generator fused into the first inverse FFT pass."""
+        out = self.empty(REAL)
+        _lib.call("fb_realise_density_device", self._plan, int(seed) & (2 ** 64 - 1),
+                  int(realisation) & (2 ** 64 - 1), self._scratch_half().ptr, out.ptr, self.stream)
+        return out
+
+    def power_fused(self, real, pre_exp=False, keep_spectrum=False):
+        """Asynchronous r2c + shell binning (cubic boxes).  Returns (results buffer, spectrum or None);
+        results = [2*nbins+1] doubles on the device, fetched with `fetch_results`."""
+        res = self._alloc_bytes((2 * self._nbins + 1) * 8)
+        work = self.empty(HALF) if keep_spectrum else self._scratch_half()
+        _lib.call("fb_power_spectrum_device", self._plan, real.ptr, work.ptr, 1 if pre_exp else 0,
+                  1 if keep_spectrum else 0, res.ptr, self.stream)
+        return res, (work if keep_spectrum else None)
+
+    def fetch_results(self, res, nbins):
+        h = np.empty(2 * nbins + 1)
+        _lib.call("fb_memcpy_d2h", _ptr(h), res.ptr, h.nbytes, self.stream)
+        return h[0:2 * nbins:2].copy(), h[1:2 * nbins:2].copy(), h[2 * nbins]
+
+    def bin_counts(self):
+        c = np.zeros(self._nbins)
+        _lib.call("fb_bin_counts", self._plan, c.ctypes.data_as(_lib.P_double))
+        return c
+
+    # -- profiling ------------------------------------------------------------------------
+    PROF_NAMES = ("fft_strided", "fft_contig", "colour", "bin", "filter", "velpot", "realop", "rsd", "layout",
+                  "fft_gen", "fft_bin")
+
+    def profile_start(self):
+        _lib.call("fb_profile_start", self._plan)
+
+    def profile_stop(self):
+        """{kernel class: (total ms, launches)} measured with HIP events on the launch stream."""
+        n = len(self.PROF_NAMES)
+        ms = (ctypes.c_double * n)()
+        cnt = (ctypes.c_int64 * n)()
+        _lib.call("fb_profile_stop", self._plan, self.stream, ms, cnt, n)
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(self.PROF_NAMES)}
 
     def sum_real(self, real, squared=False):
         v = ctypes.c_double()

@@ -70,8 +70,13 @@ int fb_set_amplitude_shells(fb_plan* plan, const double* amp, int64_t nshell);
 int fb_set_amplitude_dense(fb_plan* plan, const void* amp_dev);
 /* parity mode: re, im are the reference's np.random.normal draws, T[N][N][N] on the device  */
 int fb_colour_noise(fb_plan* plan, const void* re, const void* im, void* half_out, void* stream);
-/* throughput mode: Philox4x32-10 keyed by seed, counter = (mode index, realisation)         */
-int fb_colour_philox(fb_plan* plan, uint64_t seed, uint64_t realisation, void* half_out, void* stream);
+/* throughput mode: Threefry4x32-20 keyed by (seed, realisation), counter = mode index        */
+int fb_colour_device(fb_plan* plan, uint64_t seed, uint64_t realisation, void* half_out, void* stream);
+
+/* fused throughput path: generator inside the first inverse pass, then y and z (c2r) passes.
+ * real_out = Re ifftn(X)/1 with numpy's 1/N^3; work_half is scratch (half-spectrum sized).  */
+int fb_realise_density_device(fb_plan* plan, uint64_t seed, uint64_t realisation, void* work_half,
+                              void* real_out, void* stream);
 
 /* ---- binned power spectrum (binned_power_spectrum, box.py:741-764) ------------------------- */
 /* edges[nbins] as in np.digitize(k, edges).  thr/amb describe, for cubic boxes, the bin as a
@@ -83,6 +88,15 @@ int fb_set_bins(fb_plan* plan, const double* edges, int nbins, const int32_t* th
  * sumsq[nbins] = sum |dk|^4.  Synchronises the stream.                                       */
 int fb_bin_power(fb_plan* plan, const void* spec, int layout, double* count, double* sum, double* sumsq,
                  void* stream);
+
+/* fused path for cubic boxes (needs fb_set_bins with thr): r2c of real_in (of exp(real_in) when
+ * pre_exp) with the binning inside the last pass.  Asynchronous: results_dev[2*nbins+1] (DEVICE)
+ * receives (sum |dk|^2, sum |dk|^4) per bin, then sum(exp(real_in)) (0 unless pre_exp).
+ * work_half is scratch and holds fftn(real_in) afterwards only if keep_spectrum.              */
+int fb_power_spectrum_device(fb_plan* plan, const void* real_in, void* work_half, int pre_exp,
+                             int keep_spectrum, double* results_dev, void* stream);
+/* number of full-grid modes per bin for the current bin set (host array, nbins doubles) */
+int fb_bin_counts(fb_plan* plan, double* count);
 
 /* ---- transfer functions (apply_transfer_fn box.py:374-379, smooth_field :651-653) ---------- */
 #define FB_FILT_TABLE 0          /* table: real multiplier, same layout as the field */
@@ -101,7 +115,7 @@ int fb_potential_k(fb_plan* plan, const void* dk, void* out, int layout, void* s
 /* out = exp(in)/mean(exp(in)) - 1 (box.py:457-460); *mean_out receives mean(exp(in)). Synchronises. */
 int fb_lognormal(fb_plan* plan, const void* real_in, void* real_out, double* mean_out, void* stream);
 /* redshift_space_density (box.py:405-437). noise: T[N][N][N] standard normals in LOS order
- * (parity) or NULL -> Philox(seed) when sigma_nl > 0.                                             */
+ * (parity) or NULL -> Threefry(seed) when sigma_nl > 0.                                           */
 int fb_redshift_space(fb_plan* plan, const void* delta, const void* vz, const void* noise, void* out,
                       double Hz, double sigma_nl, uint64_t seed, void* stream);
 /* sum(x) / sum(x^2) over a real field; sum |dk|^2 over the FULL grid from a half spectrum
@@ -112,6 +126,24 @@ int fb_sumsq_half(fb_plan* plan, const void* half, double* out, void* stream);
 /* ---- layout conversion -------------------------------------------------------------------------- */
 int fb_expand_half(fb_plan* plan, const void* half, void* full, void* stream);  /* Hermitian extension */
 int fb_crop_full(fb_plan* plan, const void* full, void* half, void* stream);    /* keep k_z <= N/2      */
+
+/* ---- per-kernel timing with HIP events on the launch stream ---------------------------------------- */
+#define FB_PROF_FFT_STRIDED 0   /* x / y passes of the 3-D FFT            */
+#define FB_PROF_FFT_CONTIG 1    /* z pass (c2c, r2c, c2r)                 */
+#define FB_PROF_COLOUR 2
+#define FB_PROF_BIN 3
+#define FB_PROF_FILTER 4
+#define FB_PROF_VELPOT 5
+#define FB_PROF_REALOP 6
+#define FB_PROF_RSD 7
+#define FB_PROF_LAYOUT 8
+#define FB_PROF_FFT_GEN 9       /* x pass with the fused Gaussian generator */
+#define FB_PROF_FFT_BIN 10      /* x pass with the fused shell binning      */
+#define FB_PROF_NCAT 11
+/* between start and stop every kernel launch of this plan is bracketed by an event pair;
+ * stop synchronises and returns summed milliseconds and launch counts per class above.  */
+int fb_profile_start(fb_plan* plan);
+int fb_profile_stop(fb_plan* plan, void* stream, double* ms, int64_t* launches, int ncat);
 
 /* ---- device memory helpers for bindings without their own allocator ---------------------------- */
 int fb_malloc(void** dev_ptr, size_t bytes);

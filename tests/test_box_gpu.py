@@ -203,14 +203,14 @@ def test_reference_unit_tests_behaviour():
 
 
 @pytest.mark.parametrize("precision", ["f32", "f64"])
-def test_philox_mode_statistics(precision):
+def test_device_rng_statistics(precision):
     """Throughput RNG: not the numpy stream, so checked statistically -- P(k) of the realised
     field follows the input spectrum (chi^2 over well-populated bins), Parseval holds, runs
     are reproducible per (seed, realisation) and differ between realisations."""
     from fastbox_amd import CosmoBox, default_cosmo
     N = 64
     box = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False, precision=precision,
-                   rng="philox", seed=1234)
+                   rng="device", seed=1234)
     a = np.asarray(box.realise_density()).copy()
     kc, pk, err = box.binned_power_spectrum(nbins=20)
     s1, s2 = box.test_parseval()
@@ -218,7 +218,7 @@ def test_philox_mode_statistics(precision):
     b = np.asarray(box.realise_density()).copy()
     assert not np.allclose(a, b)
     box2 = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False, precision=precision,
-                    rng="philox", seed=1234)
+                    rng="device", seed=1234)
     assert np.array_equal(np.asarray(box2.realise_density()), a)
     # expectation: <|delta_k|^2>/boxfactor = P(k)/2 per mode (the reference's "variance too
     # high by 2x" comment, box.py:176, refers to X; Re ifftn halves it) -> compare with oracle
@@ -235,3 +235,52 @@ def test_philox_mode_statistics(precision):
     z = (pk[good] - want[good]) / (err[good] * np.sqrt(1 + 0.25))
     assert np.all(np.abs(z) < 6.0) and np.sqrt(np.mean(z ** 2)) < 2.5
     assert abs(np.mean(a)) < 1e-4 * np.std(a) + 1e-6
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 3e-5), ("f64", 1e-11)])
+@pytest.mark.parametrize("N,L", [(16, 2e2), (64, 1e3), (32, (3e2, 5e2, 1e3))])
+def test_device_rng_field_reproduced_on_host(N, L, precision, tol):
+    """rng='device' (generator fused into the first FFT pass): the realised field must equal
+    irfftn of the host model's coloured noise (fastbox_amd/rng.py), for cubic (shell table)
+    and cuboid (dense table) boxes."""
+    from fastbox_amd import CosmoBox, default_cosmo, rng
+    box = CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, precision=precision,
+                   rng="device", seed=99)
+    box.realise_density()                      # realisation 0
+    got = np.asarray(box.realise_density())    # realisation 1
+    geo = bo.box_geometry(L, N)
+    z = rng.half_spectrum_noise(N, 99, 1, np.float32 if precision == "f32" else np.float64)
+    k = bo.k_magnitude(geo)[:, :, :N // 2 + 1]
+    pk = np.nan_to_num(standin.pk_fn(standin.cosmology(), 1.0)(k.flatten())).reshape(k.shape)
+    amp = np.sqrt(pk * geo["boxfactor"])
+    pf = np.full(N // 2 + 1, np.sqrt(0.5)); pf[0] = pf[-1] = 1.0
+    want = np.fft.irfftn(z * amp * pf[None, None, :], s=(N, N, N), axes=(0, 1, 2))
+    assert np.max(np.abs(got - want)) < tol * np.std(want)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("nbins", [20, 50, 256])
+def test_fused_binning_equals_unfused(precision, nbins):
+    """binned_power_spectrum(delta_x=...) (binning fused into the last FFT pass, shell
+    thresholds) against the stored-spectrum path (separate kernel) on the same field, and
+    the lazy log-normal (exp fused into the r2c pass) against the materialised one."""
+    from fastbox_amd import CosmoBox, default_cosmo
+    np.random.seed(21)
+    box = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=64, realise_now=False, precision=precision)
+    dx = box.realise_density()
+    tol = 1e-6 if precision == "f32" else 1e-12
+    a = box.binned_power_spectrum(delta_x=dx, nbins=nbins)
+    b = box.binned_power_spectrum(nbins=nbins)
+    assert np.array_equal(a[0], b[0]) and _pk_close(a[1:], b[1:], tol)
+    kb = np.concatenate([[box.kmin], np.linspace(1.5 * box.kmin, 0.45 * box.kmax, 9)])   # edge on a shell
+    a = box.binned_power_spectrum(delta_x=dx, kbins=kb)
+    b = box.binned_power_spectrum(kbins=kb)
+    assert _pk_close(a[1:], b[1:], tol)
+    ln = box.lognormal(dx)
+    lazy = box.binned_power_spectrum(delta_x=ln, nbins=nbins)
+    assert not ln.materialised
+    mat = box.binned_power_spectrum(delta_x=np.asarray(ln), nbins=nbins)
+    assert ln.materialised
+    assert _pk_close(lazy[1:], mat[1:], 2e-5 if precision == "f32" else 1e-11)
+    pend = box.binned_power_spectrum(delta_x=dx, nbins=nbins, wait=False)
+    assert _pk_close(pend.result()[1:], box.binned_power_spectrum(delta_x=dx, nbins=nbins)[1:], 0)
