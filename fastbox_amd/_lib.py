@@ -26,6 +26,7 @@ SIGNATURES = {
                                P_double, P_double, P_double, P_double]),
     "fb_plan_destroy": (c_int, [c_void_p]),
     "fb_half_pitch": (c_int, [c_void_p]),
+    "fb_half_rows": (c_int, [c_void_p]),
     "fb_real_bytes": (c_i64, [c_void_p]),
     "fb_half_bytes": (c_i64, [c_void_p]),
     "fb_full_bytes": (c_i64, [c_void_p]),
@@ -51,6 +52,7 @@ SIGNATURES = {
     "fb_realise_density_device": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p, c_void_p]),
     "fb_power_spectrum_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fb_bin_counts": (c_int, [c_void_p, P_double]),
+    "fb_debug_strided_pass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fb_profile_start": (c_int, [c_void_p]),
     "fb_profile_stop": (c_int, [c_void_p, c_void_p, P_double, ctypes.POINTER(c_i64), c_int]),
     "fb_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size_t]),

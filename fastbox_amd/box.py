@@ -321,8 +321,8 @@ class CosmoBox(object):
             raise TypeError("complex-valued transfer functions are not supported on the device")
         t = np.broadcast_to(t, (N, N, N)).astype(self.engine.rdtype)
         if layout_kind == HALF:
-            padded = np.zeros((N, N, self.engine.pitch), dtype=self.engine.rdtype)
-            padded[:, :, :N // 2 + 1] = t[:, :, :N // 2 + 1]
+            padded = np.zeros((N, self.engine.rows, self.engine.pitch), dtype=self.engine.rdtype)
+            padded[:, :N, :N // 2 + 1] = t[:, :, :N // 2 + 1]
             t = padded
         return self.engine.upload_raw(t)
 

@@ -63,8 +63,14 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
     p->N = N; p->prec = precision; p->device = device;
     p->L[0] = Lx; p->L[1] = Ly; p->L[2] = Lz;
     p->cubic = (Lx == Ly && Ly == Lz);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            p->num_cu = prop.multiProcessorCount;
+    }
     p->NZV = N / 2 + 1;
     p->NZP = (p->NZV + 15) & ~15;
+    p->NR = N + 1;
     int r = precision == 4 ? make_twiddles<float>(&p->tw, N) : make_twiddles<double>(&p->tw, N);
     if (!r) r = upload(&p->axis2, axis2, (size_t)3 * N);
     if (!r) r = upload(&p->ksc, ksc, (size_t)3 * N);
@@ -92,8 +98,9 @@ int fb_plan_destroy(fb_plan* p) {
 }
 
 int fb_half_pitch(const fb_plan* p) { return p ? p->NZP : 0; }
+int fb_half_rows(const fb_plan* p) { return p ? p->NR : 0; }
 int64_t fb_real_bytes(const fb_plan* p) { return p ? (int64_t)p->N * p->N * p->N * p->prec : 0; }
-int64_t fb_half_bytes(const fb_plan* p) { return p ? (int64_t)p->N * p->N * p->NZP * 2 * p->prec : 0; }
+int64_t fb_half_bytes(const fb_plan* p) { return p ? (int64_t)p->N * p->NR * p->NZP * 2 * p->prec : 0; }
 int64_t fb_full_bytes(const fb_plan* p) { return p ? (int64_t)p->N * p->N * p->N * 2 * p->prec : 0; }
 
 int fb_fft_c2c(fb_plan* p, void* d, int direction, double scale, void* stream) {
@@ -250,6 +257,12 @@ int fb_bin_counts(fb_plan* p, double* count) {
     FB_REQUIRE(p->nbins > 0, "bin edges not set");
     for (int q = 0; q < p->nbins; ++q) count[q] = p->counts_host[q];
     return FB_OK;
+}
+
+int fb_debug_strided_pass(fb_plan* p, void* half, int axis, int mode, void* stream) {
+    FB_REQUIRE(p && half, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_debug_pass_f32(p, half, axis, mode, s), fbi_debug_pass_f64(p, half, axis, mode, s));
 }
 
 int fb_profile_start(fb_plan* p) {

@@ -63,6 +63,29 @@ template <int R, int SIGN, typename T> __device__ __forceinline__ void dft(cx<T>
     else dft8<SIGN>(u);
 }
 
+// ---- buffer (SRSRC) access: wave-uniform 64-bit base in scalar registers + one 32-bit
+// per-lane byte offset.  Offsets at or beyond FB_BUF_RANGE are dropped by the hardware range
+// check (loads return 0, stores are ignored), which doubles as the column-validity predicate.
+#define FB_BUF_RANGE 0xFFFFFFF0u
+#define FB_BUF_OOB 0xFFFFFFF8u
+typedef unsigned int fb_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int fb_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)FB_BUF_RANGE, 0x00020000);
+}
+__device__ __forceinline__ cx<float> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, const cx<float>*) {
+    return __builtin_bit_cast(cx<float>, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0));
+}
+__device__ __forceinline__ cx<double> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, const cx<double>*) {
+    return __builtin_bit_cast(cx<double>, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, cx<float> v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fb_u32x2, v), r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, cx<double> v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fb_u32x4, v), r, (int)voff, 0, 0);
+}
+
 constexpr int fb_min(int a, int b) { return a < b ? a : b; }
 constexpr int fb_max(int a, int b) { return a > b ? a : b; }
 

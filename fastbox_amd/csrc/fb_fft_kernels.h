@@ -15,14 +15,21 @@
 
 namespace fb {
 
+// elements per thread of the strided passes (16 = two radix-8 butterflies per stage was
+// measured slower on MI355X: 8 waves per CU cannot hide the LDS-exchange latency)
+constexpr int strided_elems(int n) { return fb_min(8, n); }
+
 // columns per tile of the strided pass: one 128-byte row segment, shrunk so the
-// tile stays within 64 KiB of LDS (two workgroups per CU).
+// tile stays within 64 KiB of LDS (two workgroups per CU), and widened for tiny grids so
+// that a workgroup is at least one full wave.
 template <typename T> constexpr int tile_cols(int n) {
-    // ... and widened for tiny grids so that a workgroup is at least one full wave
     return fb_max(fb_max(2, fb_min(128 / (2 * (int)sizeof(T)), 65536 / (n * 2 * (int)sizeof(T)))),
-                  64 / (n / elems_per_thread(n)));
+                  64 / (n / strided_elems(n)));
 }
 
+#ifndef FB_OCC
+#define FB_OCC(x) 1      // let the allocator use what the prefetching loop needs (no spills)
+#endif
 enum { SMODE_PLAIN = 0, SMODE_GEN = 1, SMODE_BIN = 2 };
 
 template <typename T> struct StridedArgs {
@@ -30,20 +37,22 @@ template <typename T> struct StridedArgs {
     cx<T>* out;
     const cx<T>* tw;         // W_N^j
     long long stride;        // elements between consecutive points of a line
-    long long outer_stride;  // elements between tiles along blockIdx.y
+    long long outer_stride;  // elements between tiles along the outer index
     int ncols;               // valid contiguous columns
     T scale;
+    int ntx;                 // tiles per outer index = ceil(ncols / TZ)      (set by the launcher)
+    int ntiles;              // ntx * (number of outer indices)               (set by the launcher)
 };
 
 // operands of the fused modes (x pass of a half spectrum: line index = k_x,
-// blockIdx.y = k_y, column = k_z)
+// outer index = k_y, column = k_z)
 template <typename T> struct StridedOp {
     KGeom g;
     AmpSrc<T> amp;       // GEN
     RngKey key;          // GEN
     const int* thr;      // BIN: shell thresholds (cubic boxes only)
     const double* bins;  // BIN: edges, for the shells listed in amb[]
-    double* partial;     // BIN: [gridDim.y * gridDim.x][2 * nbins]
+    double* partial;     // BIN: [gridDim.x][2 * nbins]
     int nbins, namb, store;
     int amb[8];
 };
@@ -68,10 +77,15 @@ __device__ __forceinline__ void wave_flush(int b, double s1, double s2, bool hav
     }
 }
 
-template <typename T, int N, int MODE>
-__global__ __launch_bounds__(tile_cols<T>(N) * (N / elems_per_thread(N)))
+// Persistent workgroups: each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and issues
+// the global loads of its next tile before transforming the current one, so that HBM requests
+// stay in flight through the LDS exchanges and the fused epilogue.
+// PERSIST = false: one tile per workgroup, two workgroups per CU (<= 64 VGPRs at 1024 threads).
+template <typename T, int N, int MODE, bool PERSIST>
+__global__ __launch_bounds__(tile_cols<T>(N) * (N / strided_elems(N)),
+                             PERSIST ? 1 : fb_min(8, fb_max(1, 2 * tile_cols<T>(N) * (N / strided_elems(N)) / 256)))
 void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
-    constexpr int E = elems_per_thread(N);
+    constexpr int E = strided_elems(N);
     constexpr int TPL = N / E;
     constexpr int TZ = tile_cols<T>(N);
     constexpr int NT = TZ * TPL;
@@ -79,126 +93,182 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<T>* tile = reinterpret_cast<cx<T>*>(smem);
     cx<T>* twl = tile + N * TZ;
+    double* acc = reinterpret_cast<double*>(twl + N);          // BIN: [NW][2 nbins], whole launch
+    int* lthr = reinterpret_cast<int*>(acc + (size_t)NW * 2 * (MODE == SMODE_BIN ? op.nbins : 0));
 
     const int tid = threadIdx.x;
     const int c = tid % TZ;
     const int t = tid / TZ;
     for (int i = tid; i < N; i += NT) twl[i] = a.tw[i];
+    if constexpr (MODE == SMODE_BIN) {
+        for (int i = tid; i < NW * 2 * op.nbins; i += NT) acc[i] = 0.0;
+        for (int i = tid; i < op.nbins; i += NT) lthr[i] = op.thr[i];
+    }
+    TileLayout<T, TZ> lay{tile, c};
 
-    const int col = blockIdx.x * TZ + c;
-    const bool valid = col < a.ncols;
-    const long long base = (long long)blockIdx.y * a.outer_stride + col;
+    // addressing: wave-uniform 64-bit tile/row base (scalar registers) + one 32-bit per-lane
+    // element offset shared by all E rows, so the E loads/stores cost no address VGPRs
+    const unsigned loff = (unsigned)(((long long)t * a.stride + c) * (long long)sizeof(cx<T>));
+    const long long estep = (long long)TPL * a.stride;
 
     cx<T> v[E];
-    if constexpr (MODE == SMODE_GEN) {
-        // generator mode k_x = t + j TPL (< N/2) also serves k_x + N/2 (fb_rng.h)
-        const int ky = blockIdx.y;
-        const int my = mode_of(ky, N);
-        const int c2 = my * my + col * col;            // col = k_z <= N/2 is its own mode number
-        const T pf = plane_factor<T>(col, N);
+    [[maybe_unused]] cx<T> vn[E];
+    int tile_id = blockIdx.x;
+    if constexpr (MODE != SMODE_GEN && PERSIST) {          // the launcher guarantees gridDim.x <= ntiles
+        const int bx0 = tile_id % a.ntx;
+        const cx<T>* src = a.in + ((long long)(tile_id / a.ntx) * a.outer_stride + bx0 * TZ);
+        const unsigned voff = bx0 * TZ + c < a.ncols ? loff : FB_BUF_OOB;
 #pragma unroll
-        for (int j = 0; j < E / 2; ++j) {
-            const int kx = t + j * TPL;
-            if (valid) {
-                const unsigned long long idx = ((unsigned long long)kx * N + ky) * op.g.NZV + col;
-                T a0, a1, b0, b1;
-                mode_noise_pair<T>(idx, 0u, op.key, a0, a1, b0, b1);
-                T A0, A1;
-                if (op.amp.shell) {
-                    const int mh = kx - (N >> 1);
-                    A0 = op.amp.shell[kx * kx + c2] * pf;
-                    A1 = op.amp.shell[mh * mh + c2] * pf;
+        for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + e * estep), voff, src);
+        if constexpr (MODE != SMODE_BIN) {
+            // E stores that the range check discards: they make the memory-op queue at loop entry
+            // look like the queue at the back edge (E loads, then E stores), so that the compiler's
+            // merged s_waitcnt for "previous prefetch has landed" is vmcnt(E) on both paths instead
+            // of a vmcnt(0) that would also drain the previous tile's stores every iteration.
+#pragma unroll
+            for (int e = 0; e < E; ++e) buf_store(make_rsrc(a.out), FB_BUF_OOB, cx<T>{0, 0});
+        }
+    }
+    do {    // PERSIST: tiles blockIdx.x, blockIdx.x + gridDim.x, ...; otherwise exactly one tile
+        const int bx = tile_id % a.ntx, by = tile_id / a.ntx;
+        const int col = bx * TZ + c;
+        const bool valid = col < a.ncols;
+        const long long ubase = (long long)by * a.outer_stride + bx * TZ;
+
+        if constexpr (MODE == SMODE_GEN) {
+            // generator mode k_x = t + j TPL (< N/2) also serves k_x + N/2 (fb_rng.h)
+            const int my = mode_of(by, N);
+            const int c2 = my * my + col * col;            // col = k_z <= N/2 is its own mode number
+            const T pf = plane_factor<T>(col, N);
+#pragma unroll
+            for (int j = 0; j < E / 2; ++j) {
+                const int kx = t + j * TPL;
+                if (valid) {
+                    const unsigned long long idx = ((unsigned long long)kx * N + by) * op.g.NZV + col;
+                    T a0, a1, b0, b1;
+                    mode_noise_pair<T>(idx, 0u, op.key, a0, a1, b0, b1);
+                    T A0, A1;
+                    if (op.amp.shell) {
+                        const int mh = kx - (N >> 1);
+                        A0 = op.amp.shell[kx * kx + c2] * pf;
+                        A1 = op.amp.shell[mh * mh + c2] * pf;
+                    } else {
+                        A0 = op.amp.dense[((long long)kx * op.g.NR + by) * op.g.NZP + col] * pf;
+                        A1 = op.amp.dense[((long long)(kx + (N >> 1)) * op.g.NR + by) * op.g.NZP + col] * pf;
+                    }
+                    v[j] = cx<T>{A0 * a0, A0 * a1};
+                    v[j + E / 2] = cx<T>{A1 * b0, A1 * b1};
                 } else {
-                    A0 = op.amp.dense[((long long)kx * N + ky) * op.g.NZP + col] * pf;
-                    A1 = op.amp.dense[((long long)(kx + (N >> 1)) * N + ky) * op.g.NZP + col] * pf;
+                    v[j] = cx<T>{0, 0};
+                    v[j + E / 2] = cx<T>{0, 0};
                 }
-                v[j] = cx<T>{A0 * a0, A0 * a1};
-                v[j + E / 2] = cx<T>{A1 * b0, A1 * b1};
-            } else {
-                v[j] = cx<T>{0, 0};
-                v[j + E / 2] = cx<T>{0, 0};
             }
-        }
-    } else {
+        } else if constexpr (!PERSIST) {
+            const cx<T>* src = a.in + ubase;
+            const unsigned voff = valid ? loff : FB_BUF_OOB;
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (valid) v[e] = a.in[base + (long long)(t + e * TPL) * a.stride];
-            else v[e] = cx<T>{0, 0};
-        }
-    }
-    __syncthreads();
-    TileLayout<T, TZ> lay{tile, c};
-    if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
-    else if constexpr (MODE == SMODE_BIN) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);
-    else {
-        if (sign < 0) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);
-        else          fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
-    }
-    if (MODE != SMODE_BIN || op.store) {
-        if (valid) {
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                a.out[base + (long long)(t + e * TPL) * a.stride] = cscale(v[e], a.scale);
-        }
-    }
-    if constexpr (MODE == SMODE_BIN) {
-        // tile[] is free: every wave passed the barrier that ended the last exchange
-        const int nb = op.nbins;
-        double* acc = reinterpret_cast<double*>(smem);             // [NW][2 nb]
-        int* lthr = reinterpret_cast<int*>(acc + (size_t)NW * 2 * nb);
-        __syncthreads();
-        for (int i = tid; i < NW * 2 * nb; i += NT) acc[i] = 0.0;
-        for (int i = tid; i < nb; i += NT) lthr[i] = op.thr[i];
-        __syncthreads();
-        double* row = acc + (size_t)(tid >> 6) * 2 * nb;
-        const int ky = blockIdx.y;
-        const int my = mode_of(ky, N);
-        const int c2 = my * my + col * col;
-        const double w = (col == 0 || col == (N >> 1)) ? 1.0 : 2.0;
-        // |m_x| is smallest for e = 0 or E-1 and largest for e = E/2-1 or E/2
-        const int mlo = t < TPL - t ? t : TPL - t;
-        const int mhi_a = t + (E / 2 - 1) * TPL, mhi_b = N - (t + (E / 2) * TPL);
-        const int mhi = mhi_a > mhi_b ? mhi_a : mhi_b;
-        const int n2lo = mlo * mlo + c2, n2hi = mhi * mhi + c2;
-        const int blo = shell_bin(lthr, nb, n2lo), bhi = shell_bin(lthr, nb, n2hi);
-        bool hit = false;
-        for (int q = 0; q < op.namb; ++q) hit |= (op.amb[q] >= n2lo && op.amb[q] <= n2hi);
-        if (__all(!valid || (blo == bhi && !hit))) {
-            double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const double p = (double)(v[e].x * v[e].x + v[e].y * v[e].y);
-                s1 += p; s2 += p * p;
-            }
-            wave_flush(blo, w * s1, w * s2, valid && blo < nb, row);
+            for (int e = 0; e < E; ++e) v[e] = buf_load(make_rsrc(src + e * estep), voff, src);
         } else {
-            int cur = -1;
-            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = vn[e];
+            // Prefetch the next tile.  Issued unconditionally (past the last tile every lane
+            // gets the out-of-range offset, which the buffer range check turns into "no access"):
+            // a branch here makes the compiler's in-order vmcnt bookkeeping pessimistic and it
+            // then waits for these loads before the current tile's first butterfly.
+            const int nxt = tile_id + gridDim.x;
+            const int nbx = nxt % a.ntx;
+            const cx<T>* src = a.in + ((long long)(nxt / a.ntx) * a.outer_stride + nbx * TZ);
+            const unsigned voff = (nxt < a.ntiles && nbx * TZ + c < a.ncols) ? loff : FB_BUF_OOB;
+#pragma unroll
+            for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + e * estep), voff, src);
+        }
+        __syncthreads();       // twiddles/thresholds visible; LDS of the previous tile's epilogue is free
+        if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
+        else if constexpr (MODE == SMODE_BIN) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);
+        else {
+            if (sign < 0) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);
+            else          fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
+        }
+        if constexpr (MODE != SMODE_BIN) {
+            cx<T>* dst = a.out + ubase;
+            const unsigned voff = valid ? loff : FB_BUF_OOB;
+#pragma unroll
+            for (int e = 0; e < E; ++e) buf_store(make_rsrc(dst + e * estep), voff, cscale(v[e], a.scale));
+        }
+        if constexpr (MODE == SMODE_BIN) {
+            // Re-stage p = |X|^2 through LDS so that each lane bins E consecutive elements of
+            // one k_x row neighbourhood and each wave 64*E/TZ consecutive rows: a lane's modes
+            // then span a narrow range of |k| (almost always one bin) and a wave needs one
+            // reduction per distinct bin.  tile[] is free: the last exchange ended in a barrier.
+            const int nb = op.nbins;
+            T* ptile = reinterpret_cast<T*>(smem);                                     // [N][TZ]
+#pragma unroll
+            for (int e = 0; e < E; ++e) ptile[(t + e * TPL) * TZ + c] = v[e].x * v[e].x + v[e].y * v[e].y;
+            __syncthreads();
+            double* row = acc + (size_t)(tid >> 6) * 2 * nb;
+            const int my = mode_of(by, N);
+            const int my2 = my * my;
+            const int col0 = bx * TZ;
+            const int off0 = tid * E;                      // lane's E consecutive elements
+            T pv[E];
+            int n2v[E];
+            int n2lo = 0x7fffffff, n2hi = -1;
 #pragma unroll
             for (int q = 0; q < E; ++q) {
-                const int e = (q & 1) ? E - 1 - (q >> 1) : (q >> 1);      // ascending |m_x|
-                const int kx = t + e * TPL;
+                pv[q] = ptile[off0 + q];
+                const int kx = (off0 + q) / TZ, kz = col0 + (off0 + q) % TZ;
                 const int mx = mode_of(kx, N);
-                const int n2 = mx * mx + c2;
-                int b = shell_bin(lthr, nb, n2);
-                for (int z = 0; z < op.namb; ++z)
-                    if (op.amb[z] == n2) b = bin_exact(op.bins, nb, kmag_exact(op.g, kx, ky, col));
-                if (!valid) b = cur;
-                if (__any(b != cur)) {
-                    wave_flush(cur, w * s1, w * s2, valid && cur >= 0 && cur < nb, row);
-                    s1 = 0.0; s2 = 0.0; cur = b;
-                }
-                const double p = (double)(v[e].x * v[e].x + v[e].y * v[e].y);
-                s1 += p; s2 += p * p;
+                const bool ok = kz < a.ncols;
+                const int n2 = mx * mx + my2 + kz * kz;
+                n2v[q] = ok ? n2 : -1;
+                if (ok) { n2lo = n2 < n2lo ? n2 : n2lo; n2hi = n2 > n2hi ? n2 : n2hi; }
             }
-            wave_flush(cur, w * s1, w * s2, valid && cur >= 0 && cur < nb, row);
+            const bool any_ok = n2hi >= 0;
+            const int blo = any_ok ? shell_bin(lthr, nb, n2lo) : 0, bhi = any_ok ? shell_bin(lthr, nb, n2hi) : 0;
+            bool hit = false;
+            for (int z = 0; z < op.namb; ++z) hit |= (op.amb[z] >= n2lo && op.amb[z] <= n2hi);
+            if (__all(!any_ok || (bhi - blo <= 1 && !hit))) {
+                // a lane's modes fall into bin blo or blo+1: one compare against the edge
+                const int edge = (any_ok && blo < nb) ? lthr[blo] : 0x7fffffff;   // first n^2 of bin blo+1
+                double s1 = 0.0, s2 = 0.0, u1 = 0.0, u2 = 0.0;
+#pragma unroll
+                for (int q = 0; q < E; ++q) {
+                    const int kz = col0 + (off0 + q) % TZ;
+                    const double w = (n2v[q] < 0) ? 0.0 : ((kz == 0 || kz == (N >> 1)) ? 1.0 : 2.0);
+                    const double p = (double)pv[q];
+                    const bool up = n2v[q] >= edge;
+                    s1 += up ? 0.0 : w * p; s2 += up ? 0.0 : w * p * p;
+                    u1 += up ? w * p : 0.0; u2 += up ? w * p * p : 0.0;
+                }
+                wave_flush(blo, s1, s2, any_ok && blo < nb, row);
+                if (__any(any_ok && bhi > blo)) wave_flush(bhi, u1, u2, any_ok && bhi > blo && bhi < nb, row);
+            } else {
+                // rare: a lane's own modes straddle an edge (or touch a shell that needs the
+                // exact |k|): bin element by element
+#pragma unroll
+                for (int q = 0; q < E; ++q) {
+                    const int kx = (off0 + q) / TZ, kz = col0 + (off0 + q) % TZ;
+                    const int n2 = n2v[q];
+                    int bb = n2 >= 0 ? shell_bin(lthr, nb, n2) : nb;
+                    for (int z = 0; z < op.namb; ++z)
+                        if (n2 >= 0 && op.amb[z] == n2) bb = bin_exact(op.bins, nb, kmag_exact(op.g, kx, by, kz));
+                    const double w = (kz == 0 || kz == (N >> 1)) ? 1.0 : 2.0;
+                    const double p = (double)pv[q];
+                    wave_flush(bb, w * p, w * p * p, n2 >= 0 && bb < nb, row);
+                }
+            }
         }
+        if constexpr (!PERSIST) break;
+        tile_id += gridDim.x;
+    } while (tile_id < a.ntiles);
+    if constexpr (MODE == SMODE_BIN) {
         __syncthreads();
-        double* dst = op.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * nb;
+        const int nb = op.nbins;
+        double* dst = op.partial + (size_t)blockIdx.x * 2 * nb;
         for (int i = tid; i < 2 * nb; i += NT) {
-            double s = 0.0;
-            for (int wv = 0; wv < NW; ++wv) s += acc[(size_t)wv * 2 * nb + i];
-            dst[i] = s;
+            double sum = 0.0;
+            for (int w2 = 0; w2 < NW; ++w2) sum += acc[(size_t)w2 * 2 * nb + i];
+            dst[i] = sum;
         }
     }
 }
@@ -227,6 +297,7 @@ template <typename T> struct ContigArgs {
     const cx<T>* tw;        // W_M^j with M = n (c2c) or 2n (r2c / c2r)
     long long in_pitch;     // elements of the input type between lines
     long long out_pitch;    // elements of the output type between lines
+    int in_skip, out_skip;  // > 0: that side is a half spectrum with one spare row after every `skip` lines
     long long nlines;
     T scale;
     int pre_exp;            // r2c: transform exp(x) instead of x (log-normal fusion)
@@ -264,7 +335,7 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
     if constexpr (MODE == ZMODE_C2R) {
         // Z[k] = (X[k] + conj X[n-k]) + i e^{+2 pi i k/N} (X[k] - conj X[n-k]); the
         // imaginary parts of X[0], X[n] are dropped (Hermitian projection).
-        const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in) + line * a.in_pitch;
+        const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in) + (line + (a.in_skip ? line / a.in_skip : 0)) * a.in_pitch;
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -300,7 +371,7 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
         for (int e = 0; e < E; ++e) lay.at(t + e * TPL) = v[e];
         __syncthreads();
         if (valid) {
-            cx<T>* out = reinterpret_cast<cx<T>*>(a.out) + line * a.out_pitch;
+            cx<T>* out = reinterpret_cast<cx<T>*>(a.out) + (line + (a.out_skip ? line / a.out_skip : 0)) * a.out_pitch;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int k = t + e * TPL;
@@ -325,14 +396,14 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
             }
         }
     } else {
-        const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in) + line * a.in_pitch;
+        const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in) + (line + (a.in_skip ? line / a.in_skip : 0)) * a.in_pitch;
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = valid ? in[t + e * TPL] : cx<T>{0, 0};
         __syncthreads();
         if (sign_c2c < 0) fft_stages<T, NF, E, -1, TWS, 1>(v, t, twl, lay);
         else              fft_stages<T, NF, E, +1, TWS, 1>(v, t, twl, lay);
         if (valid) {
-            cx<T>* out = reinterpret_cast<cx<T>*>(a.out) + line * a.out_pitch;
+            cx<T>* out = reinterpret_cast<cx<T>*>(a.out) + (line + (a.out_skip ? line / a.out_skip : 0)) * a.out_pitch;
 #pragma unroll
             for (int e = 0; e < E; ++e) out[t + e * TPL] = cscale(v[e], a.scale);
         }

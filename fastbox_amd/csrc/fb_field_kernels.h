@@ -3,7 +3,8 @@
 //
 // Layouts (z fastest, C order like the reference's numpy arrays):
 //   real  : T      [N][N][N]
-//   half  : cx<T>  [N][N][NZP]   k_z = 0..N/2 stored (NZV = N/2+1), row pitch NZP
+//   half  : cx<T>  [N][NR][NZP]  k_z = 0..N/2 stored (NZV = N/2+1), row pitch NZP, NR = N+1 rows
+//                                per x-plane of which N are used
 //   full  : cx<T>  [N][N][N]
 #pragma once
 #include "fb_fft.h"
@@ -23,6 +24,9 @@ struct KGeom {
     const double* ksc;     // [3][N]  m * (2 pi / L_a)            box.py:254-256
     const double* kpar;    // [N]     2 pi m / Lz                 box.py:375
     int N, NZV, NZP;
+    int NR;                // rows per x-plane of a half spectrum as stored: N + 1 (the spare row
+                           // keeps the x stride off a multiple of 64 KiB, which would put every row of
+                           // a tile on the same HBM channel: tools/stride_copy.hip, 265 -> 222 us)
 };
 
 __device__ __forceinline__ void fb_sincospi(float x, float* s, float* c) { sincospif(x, s, c); }
@@ -62,7 +66,7 @@ template <typename T> struct AmpSrc {
 template <typename T>
 __device__ __forceinline__ T amp_at(const AmpSrc<T>& a, const KGeom& g, int i, int j, int l) {
     if (a.shell) return a.shell[shell_of(i, j, l, g.N)];
-    return a.dense[((long long)i * g.N + j) * g.NZP + l];
+    return a.dense[((long long)i * g.NR + j) * g.NZP + l];
 }
 
 // ---- Gaussian field, parity mode ---------------------------------------------------------
@@ -78,7 +82,7 @@ __global__ void k_colour_noise(const T* __restrict__ re, const T* __restrict__ i
     const long long a = ((long long)i * N + j) * N + l;
     const long long b = ((long long)mirror_of(i, N) * N + mirror_of(j, N)) * N + mirror_of(l, N);
     const T A = (T)0.5 * amp_at(amp, g, i, j, l);
-    out[((long long)i * N + j) * g.NZP + l] = cx<T>{A * (re[a] + re[b]), A * (im[a] - im[b])};
+    out[((long long)i * g.NR + j) * g.NZP + l] = cx<T>{A * (re[a] + re[b]), A * (im[a] - im[b])};
 }
 
 // ---- Gaussian field, throughput mode (counter-based RNG, fb_rng.h) ------------------------------
@@ -101,7 +105,7 @@ __global__ void k_colour_device(cx<T>* __restrict__ out, AmpSrc<T> amp, KGeom g,
     mode_noise_pair<T>(idx, 0u, key, a0, a1, b0, b1);
     const T A = amp_at(amp, g, i, j, l) * plane_factor<T>(l, N);
     const bool hi = i >= (N >> 1);
-    out[((long long)i * N + j) * g.NZP + l] = cx<T>{A * (hi ? b0 : a0), A * (hi ? b1 : a1)};
+    out[((long long)i * g.NR + j) * g.NZP + l] = cx<T>{A * (hi ? b0 : a0), A * (hi ? b1 : a1)};
 }
 
 // ---- shell binning of |delta_k|^2 --------------------------------------------------------------
@@ -163,7 +167,7 @@ void k_bin_half(const cx<T>* __restrict__ half, double* __restrict__ partial, KG
         for (int l = lane; l < nz; l += 64) {
             const int b = bin_of_mode(bg, g, lbins, lthr, i, j, l);
             if (b < bg.nbins) {
-                const cx<T> d = half[row * pitch + l];
+                const cx<T> d = half[(full_layout ? row : (long long)i * g.NR + j) * pitch + l];
                 const double p = (double)(d.x * d.x + d.y * d.y);
                 const double w = (full_layout || l == 0 || l == (g.N >> 1)) ? 1.0 : 2.0;
                 atomicAdd(&my[(b * rep + slot) * 2 + 0], w * p);
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void k_sumsq_half(const cx<T>* __restrict__ ha
     const long long nrows = (long long)g.N * g.N;
     for (long long row = blockIdx.x; row < nrows; row += gridDim.x)
         for (int l = threadIdx.x; l < g.NZV; l += blockDim.x) {
-            const cx<T> d = half[row * g.NZP + l];
+            const cx<T> d = half[((row / g.N) * g.NR + row % g.N) * g.NZP + l];
             const double p = (double)d.x * d.x + (double)d.y * d.y;
             s += (l == 0 || l == (g.N >> 1)) ? p : 2.0 * p;
         }
@@ -296,7 +300,7 @@ __global__ void k_apply_filter(const cx<T>* __restrict__ in, cx<T>* __restrict__
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, i = blockIdx.z;
     if (l >= nz) return;
-    const long long idx = ((long long)i * g.N + j) * pitch + l;
+    const long long idx = ((long long)i * (nz == g.NZV ? g.NR : g.N) + j) * pitch + l;
     const T m = filter_value<T>(f, g, i, j, l, idx);
     const cx<T> d = in[idx];
     out[idx] = cx<T>{nan_to_num(d.x * m), nan_to_num(d.y * m)};
@@ -310,7 +314,7 @@ __global__ void k_velocity(const cx<T>* __restrict__ dk, cx<T>* __restrict__ out
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, i = blockIdx.z;
     if (l >= nz) return;
-    const long long idx = ((long long)i * g.N + j) * pitch + l;
+    const long long idx = ((long long)i * (nz == g.NZV ? g.NR : g.N) + j) * pitch + l;
     const int ic = comp == 0 ? i : (comp == 1 ? j : l);
     const double k = kmag_exact(g, i, j, l);
     const double k2 = k * k;
@@ -330,7 +334,7 @@ __global__ void k_potential(const cx<T>* __restrict__ dk, cx<T>* __restrict__ ou
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, i = blockIdx.z;
     if (l >= nz) return;
-    const long long idx = ((long long)i * g.N + j) * pitch + l;
+    const long long idx = ((long long)i * (nz == g.NZV ? g.NR : g.N) + j) * pitch + l;
     const double k = kmag_exact(g, i, j, l);
     const double k2 = k * k;
     const cx<T> d = dk[idx];
@@ -348,8 +352,8 @@ __global__ void k_expand_half(const cx<T>* __restrict__ half, cx<T>* __restrict_
     const int j = blockIdx.y, i = blockIdx.z;
     if (l >= N) return;
     cx<T> v;
-    if (l <= (N >> 1)) v = half[((long long)i * N + j) * g.NZP + l];
-    else v = cconj(half[((long long)mirror_of(i, N) * N + mirror_of(j, N)) * g.NZP + (N - l)]);
+    if (l <= (N >> 1)) v = half[((long long)i * g.NR + j) * g.NZP + l];
+    else v = cconj(half[((long long)mirror_of(i, N) * g.NR + mirror_of(j, N)) * g.NZP + (N - l)]);
     full[((long long)i * N + j) * N + l] = v;
 }
 template <typename T>
@@ -358,7 +362,7 @@ __global__ void k_crop_full(const cx<T>* __restrict__ full, cx<T>* __restrict__ 
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, i = blockIdx.z;
     if (l >= g.NZV) return;
-    half[((long long)i * N + j) * g.NZP + l] = full[((long long)i * N + j) * N + l];
+    half[((long long)i * g.NR + j) * g.NZP + l] = full[((long long)i * N + j) * N + l];
 }
 
 // ---- redshift-space remap ------------------------------------------------------------------------------------

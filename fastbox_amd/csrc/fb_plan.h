@@ -17,8 +17,10 @@ struct fb_plan {
     int prec = 4;            // bytes per real: 4 (float) or 8 (double)
     double L[3] = {0, 0, 0};
     int device = 0;
+    int num_cu = 256;        // compute units of the device (persistent-grid sizing)
     int NZV = 0;             // stored k_z modes of a half spectrum: N/2+1
     int NZP = 0;             // row pitch of a half spectrum (complex elements)
+    int NR = 0;              // stored rows per x-plane of a half spectrum (N + 1: see KGeom::NR)
     int cubic = 0;           // Lx == Ly == Lz (integer shells usable)
 
     void* tw = nullptr;      // forward twiddles W_N^j, j < N, in plan precision
@@ -109,7 +111,8 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_realise_fused_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* work_half, void* real_out, \
                                 double scale, hipStream_t s); \
     int fbi_power_fused_##sfx(fb_plan* p, const void* real_in, void* work_half, int pre_exp, int store, \
-                              double* results, hipStream_t s);
+                              double* results, hipStream_t s); \
+    int fbi_debug_pass_##sfx(fb_plan* p, void* half, int axis, int mode, hipStream_t s);
 FB_DECL(f32)
 FB_DECL(f64)
 int fbi_bin_count(fb_plan* p, hipStream_t s);

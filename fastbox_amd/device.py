@@ -133,6 +133,7 @@ class Engine(object):
                   4 if precision == "f32" else 8, int(device),
                   *[t.ctypes.data_as(_lib.P_double) for t in tabs])
         self.pitch = self.lib.fb_half_pitch(self._plan)
+        self.rows = self.lib.fb_half_rows(self._plan)
         self.nbytes = {REAL: self.lib.fb_real_bytes(self._plan), HALF: self.lib.fb_half_bytes(self._plan),
                        FULL: self.lib.fb_full_bytes(self._plan)}
         self._amp_dense = None
@@ -198,10 +199,10 @@ class Engine(object):
         return h.astype(np.float64 if d.kind == REAL else np.complex128)
 
     def download_half_raw(self, d):
-        """Half spectrum as stored: (N, N, pitch) complex, columns >= N/2+1 are padding."""
-        h = np.empty((self.N, self.N, self.pitch), dtype=self.cdtype)
+        """Half spectrum as stored, (N, N, pitch) complex; columns >= N/2+1 are padding."""
+        h = np.empty((self.N, self.rows, self.pitch), dtype=self.cdtype)
         _lib.call("fb_memcpy_d2h", _ptr(h), d.ptr, h.nbytes, self.stream)
-        return h
+        return h[:, :self.N, :]
 
     def clone(self, d):
         out = self.empty(d.kind, d._as_complex)
@@ -247,8 +248,8 @@ class Engine(object):
     def set_amplitude_dense(self, amp_half):
         """amp_half: host (N, N, N/2+1) array of sqrt(P boxfactor)."""
         N = self.N
-        padded = np.zeros((N, N, self.pitch), dtype=self.rdtype)
-        padded[:, :, :N // 2 + 1] = amp_half
+        padded = np.zeros((N, self.rows, self.pitch), dtype=self.rdtype)
+        padded[:, :N, :N // 2 + 1] = amp_half
         self._amp_dense = self.upload_raw(padded)      # keep alive: the plan only borrows it
         _lib.call("fb_set_amplitude_dense", self._plan, self._amp_dense.ptr)
 

@@ -17,7 +17,9 @@
  *   - layouts are C order with z fastest, like the reference's ndarrays:
  *       real : T          [N][N][N]
  *       full : complex<T> [N][N][N]
- *       half : complex<T> [N][N][pitch], k_z = 0..N/2 stored, pitch = fb_half_pitch()
+ *       half : complex<T> [N][rows][pitch], k_z = 0..N/2 stored, pitch = fb_half_pitch(),
+ *              rows = fb_half_rows() = N + 1 of which the first N are used (the spare row keeps
+ *              the x stride off a multiple of 64 KiB; size the buffer with fb_half_bytes())
  *     A half spectrum represents the Hermitian array fftn(real field).
  *   - one plan per host thread at a time (thread compatible, not thread safe).
  */
@@ -51,6 +53,7 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
                    const double* axis2, const double* ksc, const double* kpar, const double* zgrid);
 int fb_plan_destroy(fb_plan* plan);
 int fb_half_pitch(const fb_plan* plan);          /* complex elements per (x,y) row of a half spectrum */
+int fb_half_rows(const fb_plan* plan);           /* stored rows per x-plane of a half spectrum (N + 1)   */
 int64_t fb_real_bytes(const fb_plan* plan);
 int64_t fb_half_bytes(const fb_plan* plan);
 int64_t fb_full_bytes(const fb_plan* plan);
@@ -66,7 +69,7 @@ int fb_fft_c2r(fb_plan* plan, void* half_inout, void* real_out, double scale, vo
 /* ---- Gaussian realisation (realise_density, box.py:161-187) --------------------------- */
 /* sqrt(nan_to_num(P(k)) * boxfactor): per integer shell n^2=i^2+j^2+l^2 (cubic boxes) ...   */
 int fb_set_amplitude_shells(fb_plan* plan, const double* amp, int64_t nshell);
-/* ... or per stored mode, a DEVICE array T[N][N][pitch] (any box shape)                    */
+/* ... or per stored mode, a DEVICE array T[N][rows][pitch] (any box shape)                 */
 int fb_set_amplitude_dense(fb_plan* plan, const void* amp_dev);
 /* parity mode: re, im are the reference's np.random.normal draws, T[N][N][N] on the device  */
 int fb_colour_noise(fb_plan* plan, const void* re, const void* im, void* half_out, void* stream);
@@ -144,6 +147,10 @@ int fb_crop_full(fb_plan* plan, const void* full, void* half, void* stream);    
  * stop synchronises and returns summed milliseconds and launch counts per class above.  */
 int fb_profile_start(fb_plan* plan);
 int fb_profile_stop(fb_plan* plan, void* stream, double* ms, int64_t* launches, int ncat);
+
+/* tuning aid: a single strided FFT pass over a half spectrum (axis 0 = x, 1 = y;
+ * mode 0 plain in place, 1 fused generator, 2 fused binning without store) */
+int fb_debug_strided_pass(fb_plan* plan, void* half, int axis, int mode, void* stream);
 
 /* ---- device memory helpers for bindings without their own allocator ---------------------------- */
 int fb_malloc(void** dev_ptr, size_t bytes);
