@@ -265,6 +265,13 @@ int fb_debug_strided_pass(fb_plan* p, void* half, int axis, int mode, void* stre
     return FB_DISPATCH(p, fbi_debug_pass_f32(p, half, axis, mode, s), fbi_debug_pass_f64(p, half, axis, mode, s));
 }
 
+int fb_debug_read_stamps(fb_plan* p, long long* host, int64_t count) {
+    FB_REQUIRE(p && host && p->bin_partials, "no stamps");
+    FB_HIP(hipDeviceSynchronize());
+    FB_HIP(hipMemcpy(host, p->bin_partials, (size_t)count * sizeof(long long), hipMemcpyDeviceToHost));
+    return FB_OK;
+}
+
 int fb_profile_start(fb_plan* p) {
     FB_REQUIRE(p, "null pointer");
     p->prof_used = 0;

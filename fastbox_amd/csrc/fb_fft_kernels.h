@@ -52,7 +52,7 @@ template <typename T> struct StridedOp {
     RngKey key;          // GEN
     const int* thr;      // BIN: shell thresholds (cubic boxes only)
     const double* bins;  // BIN: edges, for the shells listed in amb[]
-    double* partial;     // BIN: [gridDim.x][2 * nbins]
+    double* partial;     // BIN: [2 * nbins][gridDim.x]
     int nbins, namb, store;
     int amb[8];
 };
@@ -105,6 +105,13 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         for (int i = tid; i < op.nbins; i += NT) lthr[i] = op.thr[i];
     }
     TileLayout<T, TZ> lay{tile, c};
+#ifdef FB_STAMPS      // diagnostic build only: phase time stamps of every workgroup (tools/stamps.py)
+    long long* stamp = reinterpret_cast<long long*>(const_cast<double*>(op.bins)) + (size_t)blockIdx.x * 8;
+#define FB_STAMP(k) do { if (tid == 0) stamp[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    FB_STAMP(0);
+#else
+#define FB_STAMP(k) do {} while (0)
+#endif
 
     // addressing: wave-uniform 64-bit tile/row base (scalar registers) + one 32-bit per-lane
     // element offset shared by all E rows, so the E loads/stores cost no address VGPRs
@@ -140,13 +147,20 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             const int my = mode_of(by, N);
             const int c2 = my * my + col * col;            // col = k_z <= N/2 is its own mode number
             const T pf = plane_factor<T>(col, N);
+            uint32_t ctr[E / 2][4], rnd[E / 2][4];
+#pragma unroll
+            for (int j = 0; j < E / 2; ++j) {
+                const unsigned long long idx = ((unsigned long long)(t + j * TPL) * N + by) * op.g.NZV + col;
+                ctr[j][0] = (uint32_t)idx; ctr[j][1] = (uint32_t)(idx >> 32); ctr[j][2] = 0u; ctr[j][3] = 0u;
+            }
+            threefry4x32_20_batch<E / 2>(ctr, op.key.k, rnd);
 #pragma unroll
             for (int j = 0; j < E / 2; ++j) {
                 const int kx = t + j * TPL;
                 if (valid) {
-                    const unsigned long long idx = ((unsigned long long)kx * N + by) * op.g.NZV + col;
                     T a0, a1, b0, b1;
-                    mode_noise_pair<T>(idx, 0u, op.key, a0, a1, b0, b1);
+                    box_muller(rnd[j][0], rnd[j][1], a0, a1);
+                    box_muller(rnd[j][2], rnd[j][3], b0, b1);
                     T A0, A1;
                     if (op.amp.shell) {
                         const int mh = kx - (N >> 1);
@@ -182,13 +196,20 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 #pragma unroll
             for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + e * estep), voff, src);
         }
+#ifdef FB_STAMPS
+        FB_STAMP(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FB_STAMP(2);
+#endif
         __syncthreads();       // twiddles/thresholds visible; LDS of the previous tile's epilogue is free
+        FB_STAMP(3);
         if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
         else if constexpr (MODE == SMODE_BIN) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);
         else {
             if (sign < 0) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);
             else          fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
         }
+        FB_STAMP(4);
         if constexpr (MODE != SMODE_BIN) {
             cx<T>* dst = a.out + ubase;
             const unsigned voff = valid ? loff : FB_BUF_OOB;
@@ -210,6 +231,34 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             const int my2 = my * my;
             const int col0 = bx * TZ;
             const int off0 = tid * E;                      // lane's E consecutive elements
+            // Interior tiles (no k_z = 0 or N/2 column, no padding column: all but the first and
+            // last tile of a row) with the lane's elements inside one k_x row take a short path:
+            // every mode counts twice and n^2 is monotonic in k_z, so two threshold searches decide.
+            bool done = false;
+            if constexpr (TZ % E == 0) {
+                if (col0 > 0 && col0 + TZ <= (N >> 1)) {
+                    const int mx = mode_of(off0 / TZ, N);
+                    const int kz0 = col0 + off0 % TZ;
+                    const int n2lo = mx * mx + my2 + kz0 * kz0;
+                    const int n2hi = mx * mx + my2 + (kz0 + E - 1) * (kz0 + E - 1);
+                    const int blo = shell_bin(lthr, nb, n2lo), bhi = shell_bin(lthr, nb, n2hi);
+                    bool hit = false;
+                    for (int z = 0; z < op.namb; ++z) hit |= (op.amb[z] >= n2lo && op.amb[z] <= n2hi);
+                    if (__all(blo == bhi && !hit)) {
+                        T s1 = 0;
+                        double s2 = 0.0;
+#pragma unroll
+                        for (int q = 0; q < E; ++q) {
+                            const T p = ptile[off0 + q];
+                            s1 += p;
+                            s2 += (double)p * (double)p;
+                        }
+                        wave_flush(blo, 2.0 * (double)s1, 2.0 * s2, blo < nb, row);
+                        done = true;              // wave-uniform
+                    }
+                }
+            }
+            if (!done) {
             T pv[E];
             int n2v[E];
             int n2lo = 0x7fffffff, n2hi = -1;
@@ -257,29 +306,34 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     wave_flush(bb, w * p, w * p * p, n2 >= 0 && bb < nb, row);
                 }
             }
+            }   // !done
         }
+#ifdef FB_STAMPS
+        FB_STAMP(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FB_STAMP(6);
+#endif
         if constexpr (!PERSIST) break;
         tile_id += gridDim.x;
     } while (tile_id < a.ntiles);
     if constexpr (MODE == SMODE_BIN) {
         __syncthreads();
         const int nb = op.nbins;
-        double* dst = op.partial + (size_t)blockIdx.x * 2 * nb;
-        for (int i = tid; i < 2 * nb; i += NT) {
+        for (int i = tid; i < 2 * nb; i += NT) {          // partial[value][workgroup]
             double sum = 0.0;
             for (int w2 = 0; w2 < NW; ++w2) sum += acc[(size_t)w2 * 2 * nb + i];
-            dst[i] = sum;
+            op.partial[(size_t)i * gridDim.x + blockIdx.x] = sum;
         }
     }
 }
 
-// out[q] = sum_r partial[r][q], fixed order: one workgroup per column
+// out[q] = sum_r partial[q][r], fixed order: one workgroup per value
 static __global__ __launch_bounds__(256) void k_sum_columns(const double* __restrict__ partial, long long nrows,
                                                              int nvals, double* __restrict__ out) {
     __shared__ double sh[256];
     const int q = blockIdx.x;
     double s = 0.0;
-    for (long long r = threadIdx.x; r < nrows; r += 256) s += partial[r * nvals + q];
+    for (long long r = threadIdx.x; r < nrows; r += 256) s += partial[(size_t)q * nrows + r];
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {

@@ -16,6 +16,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef FB_THREEFRY_ROUNDS
+#define FB_THREEFRY_ROUNDS 20     // Random123 default; 12 is the paper's Crush-resistant minimum
+#endif
+
 namespace fb {
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return __builtin_amdgcn_alignbit(x, x, 32 - r); }
@@ -26,7 +30,7 @@ __device__ __forceinline__ void threefry4x32_20(const uint32_t (&ctr)[4], const 
 #pragma unroll
     for (int i = 0; i < 4; ++i) X[i] = ctr[i] + ks[i];
 #pragma unroll
-    for (int r = 0; r < 20; ++r) {
+    for (int r = 0; r < FB_THREEFRY_ROUNDS; ++r) {
         if ((r & 1) == 0) {
             X[0] += X[1]; X[1] = rotl32(X[1], R[r & 7][0]) ^ X[0];
             X[2] += X[3]; X[3] = rotl32(X[3], R[r & 7][1]) ^ X[2];
@@ -39,6 +43,38 @@ __device__ __forceinline__ void threefry4x32_20(const uint32_t (&ctr)[4], const 
 #pragma unroll
             for (int i = 0; i < 4; ++i) X[i] += ks[(s + i) % 5];
             X[3] += (uint32_t)s;
+        }
+    }
+}
+
+// B independent blocks, round-major, so that the B dependency chains interleave in the
+// instruction stream (each round is a 3-instruction serial chain per half block)
+template <int B>
+__device__ __forceinline__ void threefry4x32_20_batch(const uint32_t (&ctr)[B][4], const uint32_t (&key)[4],
+                                                      uint32_t (&X)[B][4]) {
+    const uint32_t ks[5] = {key[0], key[1], key[2], key[3], 0x1BD11BDAu ^ key[0] ^ key[1] ^ key[2] ^ key[3]};
+    constexpr int R[8][2] = {{10, 26}, {11, 21}, {13, 27}, {23, 5}, {6, 20}, {17, 11}, {25, 10}, {18, 20}};
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) X[b][i] = ctr[b][i] + ks[i];
+#pragma unroll
+    for (int r = 0; r < FB_THREEFRY_ROUNDS; ++r) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            if ((r & 1) == 0) {
+                X[b][0] += X[b][1]; X[b][1] = rotl32(X[b][1], R[r & 7][0]) ^ X[b][0];
+                X[b][2] += X[b][3]; X[b][3] = rotl32(X[b][3], R[r & 7][1]) ^ X[b][2];
+            } else {
+                X[b][0] += X[b][3]; X[b][3] = rotl32(X[b][3], R[r & 7][0]) ^ X[b][0];
+                X[b][2] += X[b][1]; X[b][1] = rotl32(X[b][1], R[r & 7][1]) ^ X[b][2];
+            }
+            if ((r & 3) == 3) {
+                const int s = (r + 1) >> 2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) X[b][i] += ks[(s + i) % 5];
+                X[b][3] += (uint32_t)s;
+            }
         }
     }
 }

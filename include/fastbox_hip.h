@@ -151,6 +151,8 @@ int fb_profile_stop(fb_plan* plan, void* stream, double* ms, int64_t* launches, 
 /* tuning aid: a single strided FFT pass over a half spectrum (axis 0 = x, 1 = y;
  * mode 0 plain in place, 1 fused generator, 2 fused binning without store) */
 int fb_debug_strided_pass(fb_plan* plan, void* half, int axis, int mode, void* stream);
+/* diagnostic builds (-DFB_STAMPS) only: per-workgroup phase time stamps of the last plain pass */
+int fb_debug_read_stamps(fb_plan* plan, long long* host, int64_t count);
 
 /* ---- device memory helpers for bindings without their own allocator ---------------------------- */
 int fb_malloc(void** dev_ptr, size_t bytes);

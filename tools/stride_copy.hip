@@ -8,7 +8,7 @@
 
 template <int VEC>   // bytes per lane per access: 8 or 16
 __global__ __launch_bounds__(1024) void k_tile_copy(const char* __restrict__ in, char* __restrict__ out, long long stride,
-                                                     long long outer_stride, int seg, int rows, int ntx, int ntiles) {
+                                                     long long outer_stride, int seg, int rows, int ntx, int ntiles, int mode) {
     const int lanes_per_row = seg / VEC;
     const int r0 = threadIdx.x / lanes_per_row, c = threadIdx.x % lanes_per_row;
     const int rstep = blockDim.x / lanes_per_row;
@@ -19,9 +19,12 @@ __global__ __launch_bounds__(1024) void k_tile_copy(const char* __restrict__ in,
             if (VEC == 8) {
                 double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = (r + u * rstep < rows) ? *(const double*)(in + base + (long long)(r + u * rstep) * stride) : 0.0;
+                for (int u = 0; u < 8; ++u) v[u] = (mode != 2 && r + u * rstep < rows) ? *(const double*)(in + base + (long long)(r + u * rstep) * stride) : 1.0;
+                if (mode == 1) { double acc = 0; for (int u = 0; u < 8; ++u) acc += v[u]; if (acc == 1.2345) out[0] = 1; }
+                else {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (r + u * rstep < rows) *(double*)(out + base + (long long)(r + u * rstep) * stride) = v[u];
+                }
             } else {
                 double2 v[8];
 #pragma unroll
@@ -67,8 +70,9 @@ int main() {
         {"x-like (plane + 1 row)", (long long)(N + 1) * rowbytes, rowbytes, N},
         {"x-like (plane + 256 B)", (long long)N * rowbytes + 256, rowbytes, N}};
     for (auto& cf : cfgs)
+      for (int mode : {0, 1, 2})
         for (int seg : {128, 256})
-            for (int vec : {8, 16}) {
+            for (int vec : {8}) {
                 if (seg / vec > 1024 || seg % vec) continue;
                 const int ntx = (rowbytes + seg - 1) / seg;     // last tile overruns into padding: fine for timing
                 const int ntiles = ntx * cf.nouter;
@@ -77,14 +81,14 @@ int main() {
                     float best = 1e9f;
                     for (int rep = 0; rep < 5; ++rep) {
                         hipEventRecord(e0);
-                        if (vec == 8) hipLaunchKernelGGL(k_tile_copy<8>, dim3(blocks), dim3(1024), 0, 0, a, b, cf.stride, cf.outer, seg, N, ntx, ntiles);
-                        else hipLaunchKernelGGL(k_tile_copy<16>, dim3(blocks), dim3(1024), 0, 0, a, b, cf.stride, cf.outer, seg, N, ntx, ntiles);
+                        if (vec == 8) hipLaunchKernelGGL(k_tile_copy<8>, dim3(blocks), dim3(1024), 0, 0, a, b, cf.stride, cf.outer, seg, N, ntx, ntiles, mode);
+                        else hipLaunchKernelGGL(k_tile_copy<16>, dim3(blocks), dim3(1024), 0, 0, a, b, cf.stride, cf.outer, seg, N, ntx, ntiles, mode);
                         hipEventRecord(e1); hipEventSynchronize(e1);
                         float ms; hipEventElapsedTime(&ms, e0, e1);
                         if (ms < best) best = ms;
                     }
-                    printf("%s seg %4d B  %2d B/lane  %4d blocks: %7.1f us  %6.0f GB/s\n", cf.name, seg, vec, blocks,
-                           best * 1e3, moved / best / 1e6);
+                    printf("%s %s seg %4d B  %2d B/lane  %4d blocks: %7.1f us  %6.0f GB/s\n", cf.name, mode == 0 ? "copy " : (mode == 1 ? "read " : "write"), seg, vec, blocks,
+                           best * 1e3, (mode == 0 ? moved : moved / 2) / best / 1e6);
                 }
             }
     // reference: plain contiguous float4 streams over the same buffers
