@@ -52,6 +52,15 @@ SIGNATURES = {
     "fb_realise_density_device": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p, c_void_p]),
     "fb_power_spectrum_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fb_bin_counts": (c_int, [c_void_p, P_double]),
+    "fb_slab_half_bytes": (c_i64, [c_void_p, c_int]),
+    "fb_slab_kspace_bytes": (c_i64, [c_void_p, c_int]),
+    "fb_slab_forward_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "fb_slab_inverse_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "fb_slab_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "fb_slab_unpack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "fb_slab_x_pass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fb_slab_x_generate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_u64, c_u64, c_void_p]),
+    "fb_slab_x_bin": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fb_debug_strided_pass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fb_debug_read_stamps": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), c_i64]),
     "fb_profile_start": (c_int, [c_void_p]),

@@ -259,6 +259,69 @@ int fb_bin_counts(fb_plan* p, double* count) {
     return FB_OK;
 }
 
+// ---- slab-decomposed transforms -------------------------------------------------------------------
+#define FB_SLAB_CHECK(p, nparts) \
+    FB_REQUIRE((p), "null pointer"); \
+    FB_REQUIRE((nparts) >= 1 && (p)->N % (nparts) == 0, "the number of slabs must divide N")
+
+int fb_slab_forward_local(fb_plan* p, const void* real_local, void* half_local, int nparts, int pre_exp,
+                          double* expsum_dev, void* stream) {
+    FB_SLAB_CHECK(p, nparts);
+    FB_REQUIRE(real_local && half_local, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int nxl = p->N / nparts;
+    return FB_DISPATCH(p, fbi_slab_forward_local_f32(p, real_local, half_local, nxl, pre_exp, expsum_dev, s),
+                       fbi_slab_forward_local_f64(p, real_local, half_local, nxl, pre_exp, expsum_dev, s));
+}
+int fb_slab_inverse_local(fb_plan* p, void* half_local, void* real_local, int nparts, void* stream) {
+    FB_SLAB_CHECK(p, nparts);
+    FB_REQUIRE(real_local && half_local, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int nxl = p->N / nparts;
+    const double scale = 1.0 / ((double)p->N * p->N * p->N);
+    return FB_DISPATCH(p, fbi_slab_inverse_local_f32(p, half_local, real_local, nxl, scale, s),
+                       fbi_slab_inverse_local_f64(p, half_local, real_local, nxl, scale, s));
+}
+int fb_slab_pack(fb_plan* p, const void* half_local, void* sendbuf, int nparts, void* stream) {
+    FB_SLAB_CHECK(p, nparts);
+    FB_REQUIRE(half_local && sendbuf && half_local != sendbuf, "bad buffers");
+    return fbi_slab_permute(p, half_local, sendbuf, p->N / nparts, nparts, 1, (hipStream_t)stream);
+}
+int fb_slab_unpack(fb_plan* p, const void* recvbuf, void* half_local, int nparts, void* stream) {
+    FB_SLAB_CHECK(p, nparts);
+    FB_REQUIRE(half_local && recvbuf && half_local != recvbuf, "bad buffers");
+    return fbi_slab_permute(p, recvbuf, half_local, p->N / nparts, nparts, 0, (hipStream_t)stream);
+}
+int fb_slab_x_pass(fb_plan* p, void* kslab, int nparts, int direction, void* stream) {
+    FB_SLAB_CHECK(p, nparts);
+    FB_REQUIRE(kslab && (direction == 1 || direction == -1), "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int nyl = p->N / nparts;
+    return FB_DISPATCH(p, fbi_slab_x_pass_f32(p, kslab, nyl, direction, s), fbi_slab_x_pass_f64(p, kslab, nyl, direction, s));
+}
+int fb_slab_x_generate(fb_plan* p, void* kslab, int nparts, int part, uint64_t seed, uint64_t realisation, void* stream) {
+    FB_SLAB_CHECK(p, nparts);
+    FB_REQUIRE(kslab && part >= 0 && part < nparts, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int nyl = p->N / nparts;
+    return FB_DISPATCH(p, fbi_slab_x_generate_f32(p, kslab, nyl, part * nyl, seed, realisation, s),
+                       fbi_slab_x_generate_f64(p, kslab, nyl, part * nyl, seed, realisation, s));
+}
+int fb_slab_x_bin(fb_plan* p, void* kslab, int nparts, int part, double* results_dev, void* stream) {
+    FB_SLAB_CHECK(p, nparts);
+    FB_REQUIRE(kslab && results_dev && part >= 0 && part < nparts, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int nyl = p->N / nparts;
+    return FB_DISPATCH(p, fbi_slab_x_bin_f32(p, kslab, nyl, part * nyl, results_dev, s),
+                       fbi_slab_x_bin_f64(p, kslab, nyl, part * nyl, results_dev, s));
+}
+int64_t fb_slab_half_bytes(const fb_plan* p, int nparts) {
+    return (p && nparts > 0) ? (int64_t)(p->N / nparts) * p->NR * p->NZP * 2 * p->prec : 0;
+}
+int64_t fb_slab_kspace_bytes(const fb_plan* p, int nparts) {
+    return (p && nparts > 0) ? (int64_t)p->N * (p->N / nparts) * p->NZP * 2 * p->prec : 0;
+}
+
 int fb_debug_strided_pass(fb_plan* p, void* half, int axis, int mode, void* stream) {
     FB_REQUIRE(p && half, "null pointer");
     hipStream_t s = (hipStream_t)stream;

@@ -54,6 +54,7 @@ template <typename T> struct StridedOp {
     const double* bins;  // BIN: edges, for the shells listed in amb[]
     double* partial;     // BIN: [2 * nbins][gridDim.x]
     int nbins, namb, store;
+    int outer0;          // global index of this launch's first outer (k_y) row
     int amb[8];
 };
 
@@ -144,13 +145,14 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 
         if constexpr (MODE == SMODE_GEN) {
             // generator mode k_x = t + j TPL (< N/2) also serves k_x + N/2 (fb_rng.h)
-            const int my = mode_of(by, N);
+            const int ky = by + op.outer0;             // global k_y (slab-decomposed runs own a k_y range)
+            const int my = mode_of(ky, N);
             const int c2 = my * my + col * col;            // col = k_z <= N/2 is its own mode number
             const T pf = plane_factor<T>(col, N);
             uint32_t ctr[E / 2][4], rnd[E / 2][4];
 #pragma unroll
             for (int j = 0; j < E / 2; ++j) {
-                const unsigned long long idx = ((unsigned long long)(t + j * TPL) * N + by) * op.g.NZV + col;
+                const unsigned long long idx = ((unsigned long long)(t + j * TPL) * N + ky) * op.g.NZV + col;
                 ctr[j][0] = (uint32_t)idx; ctr[j][1] = (uint32_t)(idx >> 32); ctr[j][2] = 0u; ctr[j][3] = 0u;
             }
             threefry4x32_20_batch<E / 2>(ctr, op.key.k, rnd);
@@ -167,8 +169,8 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                         A0 = op.amp.shell[kx * kx + c2] * pf;
                         A1 = op.amp.shell[mh * mh + c2] * pf;
                     } else {
-                        A0 = op.amp.dense[((long long)kx * op.g.NR + by) * op.g.NZP + col] * pf;
-                        A1 = op.amp.dense[((long long)(kx + (N >> 1)) * op.g.NR + by) * op.g.NZP + col] * pf;
+                        A0 = op.amp.dense[((long long)kx * op.g.NR + ky) * op.g.NZP + col] * pf;
+                        A1 = op.amp.dense[((long long)(kx + (N >> 1)) * op.g.NR + ky) * op.g.NZP + col] * pf;
                     }
                     v[j] = cx<T>{A0 * a0, A0 * a1};
                     v[j + E / 2] = cx<T>{A1 * b0, A1 * b1};
@@ -227,7 +229,8 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             for (int e = 0; e < E; ++e) ptile[(t + e * TPL) * TZ + c] = v[e].x * v[e].x + v[e].y * v[e].y;
             __syncthreads();
             double* row = acc + (size_t)(tid >> 6) * 2 * nb;
-            const int my = mode_of(by, N);
+            const int ky = by + op.outer0;             // global k_y (slab-decomposed runs own a k_y range)
+            const int my = mode_of(ky, N);
             const int my2 = my * my;
             const int col0 = bx * TZ;
             const int off0 = tid * E;                      // lane's E consecutive elements
@@ -300,7 +303,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     const int n2 = n2v[q];
                     int bb = n2 >= 0 ? shell_bin(lthr, nb, n2) : nb;
                     for (int z = 0; z < op.namb; ++z)
-                        if (n2 >= 0 && op.amb[z] == n2) bb = bin_exact(op.bins, nb, kmag_exact(op.g, kx, by, kz));
+                        if (n2 >= 0 && op.amb[z] == n2) bb = bin_exact(op.bins, nb, kmag_exact(op.g, kx, ky, kz));
                     const double w = (kz == 0 || kz == (N >> 1)) ? 1.0 : 2.0;
                     const double p = (double)pv[q];
                     wave_flush(bb, w * p, w * p * p, n2 >= 0 && bb < nb, row);

@@ -365,6 +365,22 @@ __global__ void k_crop_full(const cx<T>* __restrict__ full, cx<T>* __restrict__ 
     half[((long long)i * g.NR + j) * g.NZP + l] = full[((long long)i * N + j) * N + l];
 }
 
+// ---- slab-decomposed FFT: x-slab <-> all-to-all buffer ----------------------------------------
+// pack  : buf[s][xl][kyl][pitch] = half_local[xl][s*nyl + kyl][pitch]   (before the exchange)
+// unpack: half_local[xl][q*nyl + kyl][pitch] = buf[q][xl][kyl][pitch]   (after the exchange)
+// One 16-byte vector per lane along the row; rows = nparts*nyl = N.
+template <int PACK>
+__global__ void k_slab_permute(const uint4* __restrict__ in, uint4* __restrict__ out, int nxl, int nyl, int nparts,
+                               int row_vec, int plane_rows) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= row_vec) return;
+    const int ky = blockIdx.y, xl = blockIdx.z;
+    const int sidx = ky / nyl, kyl = ky % nyl;
+    const long long slab = ((long long)xl * plane_rows + ky) * row_vec + v;
+    const long long buf = (((long long)sidx * nxl + xl) * nyl + kyl) * row_vec + v;
+    if (PACK) out[buf] = in[slab]; else out[slab] = in[buf];
+}
+
 // ---- redshift-space remap ------------------------------------------------------------------------------------
 // box.py:412-437, one workgroup per line of sight: s = z - (v + sigma n)/H, periodic wrap,
 // sort (s, delta) in LDS (bitonic), then for every grid point the scipy griddata/np.interp

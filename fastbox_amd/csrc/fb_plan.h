@@ -112,7 +112,14 @@ int fb_hip_check(hipError_t e, const char* what);
                                 double scale, hipStream_t s); \
     int fbi_power_fused_##sfx(fb_plan* p, const void* real_in, void* work_half, int pre_exp, int store, \
                               double* results, hipStream_t s); \
-    int fbi_debug_pass_##sfx(fb_plan* p, void* half, int axis, int mode, hipStream_t s);
+    int fbi_debug_pass_##sfx(fb_plan* p, void* half, int axis, int mode, hipStream_t s); \
+    int fbi_slab_forward_local_##sfx(fb_plan* p, const void* real_local, void* half_local, int nxl, int pre_exp, \
+                                     double* expsum, hipStream_t s); \
+    int fbi_slab_inverse_local_##sfx(fb_plan* p, void* half_local, void* real_local, int nxl, double scale, hipStream_t s); \
+    int fbi_slab_x_pass_##sfx(fb_plan* p, void* kslab, int nyl, int sign, hipStream_t s); \
+    int fbi_slab_x_generate_##sfx(fb_plan* p, void* kslab, int nyl, int ky0, uint64_t seed, uint64_t real, hipStream_t s); \
+    int fbi_slab_x_bin_##sfx(fb_plan* p, void* kslab, int nyl, int ky0, double* results, hipStream_t s);
 FB_DECL(f32)
 FB_DECL(f64)
 int fbi_bin_count(fb_plan* p, hipStream_t s);
+int fbi_slab_permute(fb_plan* p, const void* in, void* out, int nxl, int nparts, int pack, hipStream_t s);

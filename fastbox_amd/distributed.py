@@ -1,0 +1,218 @@
+"""
+One box spread over several GPUs: slab-decomposed 3-D FFT with a single all-to-all per transform
+(the reference has no distributed code -- this is the scale-out of its
+realise_density / binned_power_spectrum for boxes whose Monte-Carlo needs strong scaling).
+
+Decomposition for P ranks (one process per GPU, ``torch.distributed``; backend "nccl" = RCCL over
+xGMI on the GPUs, "gloo" on CPUs for tests):
+
+  real space : rank r owns x-planes [r N/P, (r+1) N/P)            T[N/P][N][N]
+  k space    : rank r owns k_y rows [r N/P, (r+1) N/P) of every x-plane, stored x-major
+               kslab = complex[N][N/P][pitch]                      (k_z fastest, Hermitian half)
+
+  realise_density : generator fused into the x pass of the kslab  -> all-to-all (the kslab's N/P-plane
+                    blocks are already contiguous: no pack)       -> unpack -> y pass + z c2r
+  P(k)            : z r2c + y pass on the x-slab -> pack -> all-to-all -> the receive buffer IS the
+                    kslab -> x pass with fused shell binning -> all-reduce of 2*nbins+1 doubles
+
+Each ordered pair of ranks exchanges (N/P)(N/P)(pitch) complex values; with P = 8 all 7 xGMI links of
+a GPU carry one peer each.  The device noise depends on global mode indices only, so the field is
+identical for every P (tests compare P = 1, 2, 4).
+
+The per-rank arithmetic is behind a small "ops" interface: ``HipSlabOps`` drives libfastbox_hip (no
+CPU fallback); tests inject a numpy implementation to exercise the exchange logic under gloo.
+"""
+import ctypes
+
+import numpy as np
+
+from . import hostgeom
+
+
+class HipSlabOps(object):
+    """Per-rank HIP operations on torch CUDA tensors (data_ptr() -> C ABI, torch's current stream)."""
+
+    def __init__(self, geom, nparts, part, precision="f32", device=0):
+        import torch
+        from . import _lib
+        from .device import Engine
+        self.torch, self._lib = torch, _lib
+        self.g, self.P, self.part = geom, nparts, part
+        self.N = geom["N"]
+        self.dev = torch.device("cuda", device)
+        axis2, ksc, kpar = hostgeom.axis_tables(self.N, geom["L"])
+        self.engine = Engine(self.N, geom["L"], axis2, ksc, kpar, geom["z"], precision=precision, device=device)
+        self.rdtype = torch.float32 if precision == "f32" else torch.float64
+        self.pitch, self.rows = self.engine.pitch, self.engine.rows
+        self.nloc = self.N // nparts
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _call(self, name, *args):
+        self._lib.call(name, self.engine._plan, *args)
+
+    # buffers (complex stored as trailing dimension of 2 reals)
+    def new_real(self):
+        return self.torch.empty((self.nloc, self.N, self.N), dtype=self.rdtype, device=self.dev)
+
+    def new_half_local(self):
+        return self.torch.empty((self.nloc, self.rows, self.pitch, 2), dtype=self.rdtype, device=self.dev)
+
+    def new_kslab(self):
+        return self.torch.empty((self.N, self.nloc, self.pitch, 2), dtype=self.rdtype, device=self.dev)
+
+    def new_results(self, n):
+        return self.torch.zeros(n, dtype=self.torch.float64, device=self.dev)
+
+    # tables
+    def set_amplitude(self, amp_shells):
+        self.engine.set_amplitude_shells(amp_shells)
+
+    def set_bins(self, bins, thr, amb):
+        self.engine.set_bins(bins, thr, amb)
+
+    def bin_counts(self):
+        return self.engine.bin_counts()
+
+    # transforms
+    def x_generate(self, kslab, seed, realisation):
+        self._call("fb_slab_x_generate", kslab.data_ptr(), self.P, self.part, seed & (2 ** 64 - 1),
+                   realisation & (2 ** 64 - 1), self._stream())
+
+    def unpack(self, recv, half_local):
+        self._call("fb_slab_unpack", recv.data_ptr(), half_local.data_ptr(), self.P, self._stream())
+
+    def inverse_local(self, half_local, real):
+        self._call("fb_slab_inverse_local", half_local.data_ptr(), real.data_ptr(), self.P, self._stream())
+
+    def forward_local(self, real, half_local, pre_exp, expsum):
+        self._call("fb_slab_forward_local", real.data_ptr(), half_local.data_ptr(), self.P, 1 if pre_exp else 0,
+                   expsum.data_ptr() if pre_exp else None, self._stream())
+
+    def pack(self, half_local, send):
+        self._call("fb_slab_pack", half_local.data_ptr(), send.data_ptr(), self.P, self._stream())
+
+    def x_bin(self, kslab, results):
+        self._call("fb_slab_x_bin", kslab.data_ptr(), self.P, self.part, results.data_ptr(), self._stream())
+
+
+class SlabBox(object):
+    """The slab-decomposed counterpart of ``CosmoBox.realise_density`` / ``binned_power_spectrum``
+    for cubic boxes with the device RNG.  Collective: every rank of the group calls each method."""
+
+    def __init__(self, cosmo, box_scale=1e3, nsamp=512, redshift=0., precision="f32", seed=0,
+                 rank=None, world=None, group=None, ops_factory=None, device=None, pk_fn=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank, self.world = rank, world
+        self.g = hostgeom.grid(box_scale, nsamp)
+        N = self.N = nsamp
+        if not self.g["cubic"]:
+            raise ValueError("SlabBox needs a cubic box")
+        if N % world:
+            raise ValueError("the number of ranks must divide nsamp")
+        self.boxfactor, self.kmin, self.kmax = self.g["boxfactor"], self.g["kmin"], self.g["kmax"]
+        self.seed, self._realisation = int(seed), 0
+        if pk_fn is None:
+            from . import box as _box
+            if isinstance(cosmo, dict):
+                cosmo = _box._ccl.Cosmology(**cosmo)
+            a = 1. / (1. + redshift)
+            pk_fn = lambda k: _box._ccl.nonlin_matter_power(cosmo, k=k, a=a)
+        self.cosmo = cosmo
+        if ops_factory is None:
+            ops_factory = lambda g, P, r: HipSlabOps(g, P, r, precision=precision,
+                                                     device=(r if device is None else device))
+        self.ops = ops_factory(self.g, world, rank)
+        self.ops.set_amplitude(hostgeom.shell_amplitude(N, self.g["L"][0], self.boxfactor, pk_fn))
+        self._kslab = self.ops.new_kslab()
+        self._xbuf = self.ops.new_kslab()          # same byte count as [P][N/P][N/P][pitch]
+        self._half = self.ops.new_half_local()
+        self.delta_x = None
+
+    # -- the single data-path collective --------------------------------------------------
+    def _exchange(self, send, recv):
+        if self.world == 1:
+            recv.copy_(send)
+        else:
+            self._dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+
+    # -- realise_density (box.py:130-194, throughput mode) ------------------------------------
+    def _gen_local(self):
+        self.ops.x_generate(self._kslab, self.seed, self._realisation)
+        self._realisation += 1
+        return self._kslab
+
+    def _gen_finish(self, recv):
+        self.ops.unpack(recv, self._half)
+        real = self.ops.new_real()
+        self.ops.inverse_local(self._half, real)
+        self.delta_x = real
+        return real
+
+    def realise_density(self):
+        """This rank's x-slab of delta_x (kept in ``self.delta_x``)."""
+        send = self._gen_local()
+        self._exchange(send, self._xbuf)
+        return self._gen_finish(self._xbuf)
+
+    # -- binned_power_spectrum (box.py:696-768) ----------------------------------------------
+    def _pk_setup(self, nbins, kbins):
+        bins, kc = hostgeom.bin_edges(self.g, nbins, kbins)
+        thr, amb = hostgeom.shell_thresholds(self.N, self.g["L"][0], bins)
+        if thr is None:
+            raise ValueError("these bin edges cannot be expressed as shell thresholds")
+        self.ops.set_bins(bins, thr, amb)
+        return bins, kc
+
+    def _pk_local(self, real, lognormal, nb):
+        self._res = self.ops.new_results(2 * nb + 1)
+        self.ops.forward_local(real, self._half, lognormal, self._res[2 * nb:])
+        self.ops.pack(self._half, self._xbuf)
+        return self._xbuf
+
+    def _pk_finish(self, kslab, nb):
+        self.ops.x_bin(kslab, self._res)
+        return self._res
+
+    def binned_power_spectrum(self, delta_x=None, nbins=20, kbins=None, lognormal=False):
+        """P(k) of the distributed field (of its log-normal transform if ``lognormal``); every rank
+        returns the full (kc, pk, stddev) triple."""
+        real = self.delta_x if delta_x is None else delta_x
+        bins, kc = self._pk_setup(nbins, kbins)
+        nb = bins.size
+        if lognormal and not bins[0] > 0.:
+            raise ValueError("the fused log-normal P(k) needs kbins[0] > 0")
+        send = self._pk_local(real, lognormal, nb)
+        self._exchange(send, self._kslab)
+        res = self._pk_finish(self._kslab, nb)
+        if self.world > 1:
+            self._dist.all_reduce(res, group=self.group)          # 2*nbins+1 doubles
+        h = res.detach().cpu().numpy()
+        s1, s2, esum = h[0:2 * nb:2].copy(), h[1:2 * nb:2].copy(), h[2 * nb]
+        if lognormal:
+            mean = esum / float(self.N) ** 3
+            s1, s2 = s1 / mean ** 2, s2 / mean ** 4
+        return (kc,) + hostgeom.finish_bins(self.ops.bin_counts(), s1, s2, self.boxfactor)
+
+
+def run_virtual(boxes, fn_local, fn_finish):
+    """Drive several SlabBox objects that live in ONE process (virtual ranks, e.g. to exercise the
+    slab kernels on a single GPU): phase 1 on every rank, the all-to-all by block copies, phase 2."""
+    P = len(boxes)
+    sends = [fn_local(b) for b in boxes]
+    outs = []
+    for r, b in enumerate(boxes):
+        n = sends[0].shape[0] // P
+        recv = b._xbuf if sends[r] is not b._xbuf else b._kslab
+        flat = recv.view(P, -1)
+        for q in range(P):
+            flat[q].copy_(sends[q].view(P, -1)[r])
+        outs.append(fn_finish(b, recv))
+    return outs

@@ -1,0 +1,100 @@
+"""
+Host-side geometry of a CosmoBox that needs no GPU: grid, |k| shells, bin edges and the
+per-bin shell thresholds handed to the device.  Every expression follows the reference's
+numpy arithmetic (fastbox/box.py lines cited) so that |k| and np.digitize agree bit for bit.
+Shared by ``CosmoBox`` (single GPU) and ``SlabBox`` (one box over several GPUs).
+"""
+import numpy as np
+
+
+def grid(box_scale, nsamp):
+    """x, y, z (linspace incl. both end points), side lengths, boxfactor, kmin, kmax
+    (box.py:76-101)."""
+    if isinstance(box_scale, tuple):
+        assert len(box_scale) == 3, "Must specify scale of x, y, z dimensions"
+        x, y, z = [np.linspace(-0.5 * s, 0.5 * s, nsamp) for s in box_scale]
+    else:
+        x = y = z = np.linspace(-0.5 * box_scale, 0.5 * box_scale, nsamp)
+    L = (x[-1] - x[0], y[-1] - y[0], z[-1] - z[0])
+    boxfactor = (nsamp ** 6.) / (L[0] * L[1] * L[2])
+    kmin = 2. * np.pi / np.max(L)
+    kmax = 2. * np.pi * np.sqrt(3.) * nsamp / np.min(L)
+    return dict(N=nsamp, x=x, y=y, z=z, L=L, boxfactor=boxfactor, kmin=kmin, kmax=kmax,
+                cubic=(L[0] == L[1] == L[2]))
+
+
+def mode_numbers(N):
+    """box.py:119."""
+    return (N * np.fft.fftfreq(N, 1.)).astype("i").astype(np.float64)
+
+
+def axis_tables(N, L):
+    """(m/L)**2 per axis [3N], m*(2 pi/L) per axis [3N], 2 pi m / Lz [N]
+    (box.py:125-127, 254-256, 375)."""
+    m = mode_numbers(N)
+    axis2 = np.concatenate([(m / l) ** 2. for l in L])
+    ksc = np.concatenate([m * (2. * np.pi / l) for l in L])
+    kpar = 2. * np.pi * m / L[2]
+    return axis2, ksc, kpar
+
+
+def shell_wavenumbers(N, Lside):
+    """|k| of every integer shell n^2 = i^2 + j^2 + l^2 of a cubic box."""
+    n2 = np.arange(3 * (N // 2) ** 2 + 1, dtype=np.float64)
+    return 2. * np.pi * np.sqrt(n2) / Lside
+
+
+def shell_amplitude(N, Lside, boxfactor, pk_fn):
+    """sqrt(nan_to_num(P(k)) * boxfactor) per shell (box.py:161-171)."""
+    with np.errstate(all="ignore"):
+        pk = np.nan_to_num(np.asarray(pk_fn(shell_wavenumbers(N, Lside)), dtype=np.float64))
+        return np.sqrt(pk * boxfactor)
+
+
+def bin_edges(g, nbins=20, kbins=None):
+    """Edges and the centres of bins 1..nbins-1 (box.py:745-751)."""
+    if kbins is not None:
+        bins = np.asarray(kbins, dtype=np.float64)
+    else:
+        bins = np.logspace(np.log10(g["kmin"]), np.log10(g["kmax"]), nbins)
+    _b = [0.0] + list(bins)
+    cent = [0.5 * (_b[j + 1] + _b[j]) for j in range(bins.size)]
+    return bins, np.array(cent[1:])
+
+
+def shell_thresholds(N, Lside, bins):
+    """np.digitize(k, bins) as a step function of the integer shell (cubic boxes): thr[b] = first
+    n^2 whose bin index exceeds b.  Shells whose |k| lies within rounding of an edge cannot be
+    decided from n^2 alone (the reference's per-mode |k| differs in the last bits between
+    decompositions of the same n^2) and are returned in `amb` for the exact on-device path."""
+    if not np.all(np.diff(bins) >= 0):
+        return None, ()
+    k = shell_wavenumbers(N, Lside)
+    eps = 64 * np.finfo(np.float64).eps
+    lo = np.digitize(k * (1. - eps), bins)
+    hi = np.digitize(k * (1. + eps), bins)
+    amb = np.nonzero(lo != hi)[0]
+    if amb.size > 8:
+        return None, ()
+    thr = np.searchsorted(hi, np.arange(1, bins.size + 1), side="left")
+    return thr.astype(np.int32), tuple(int(a) for a in amb)
+
+
+def finish_bins(cnt, s1, s2, boxfactor):
+    """(mean, std/sqrt(n)) per bin from (count, sum |dk|^2, sum |dk|^4), bin 0 dropped
+    (box.py:761-768); exactly 0 spread for single-valued bins, NaN for empty ones."""
+    with np.errstate(all="ignore"):
+        vals = s1 / (cnt * boxfactor)
+        var = (s2 - s1 * s1 / cnt) / cnt
+        stddev = np.sqrt(np.maximum(var, 0.)) / boxfactor / np.sqrt(cnt)
+    return np.array(vals[1:]), np.array(stddev[1:])
+
+
+def bin_counts(N, Lside, bins):
+    """Number of modes of the full (N,N,N) grid per np.digitize index (host, cubic boxes): used
+    when no device is at hand (tests of the slab driver)."""
+    m = mode_numbers(N)
+    a = (m / Lside) ** 2.
+    k = 2. * np.pi * np.sqrt(a[:, None, None] + a[None, :, None] + a[None, None, :])
+    idx = np.digitize(k.ravel(), bins)
+    return np.bincount(idx, minlength=bins.size + 1)[:bins.size].astype(np.float64)

@@ -148,6 +148,29 @@ int fb_crop_full(fb_plan* plan, const void* full, void* half, void* stream);    
 int fb_profile_start(fb_plan* plan);
 int fb_profile_stop(fb_plan* plan, void* stream, double* ms, int64_t* launches, int ncat);
 
+/* ---- slab-decomposed 3-D FFT for one box spread over `nparts` GPUs (one process per GPU) ---------
+ * Rank `part` owns x-planes [part*N/nparts, ...) of real fields (T[N/nparts][N][N]) and, in k space,
+ * k_y rows [part*N/nparts, ...) of every x-plane: kslab = complex<T>[N][N/nparts][pitch].
+ * A forward transform is: fb_slab_forward_local (z r2c + y pass on the x-slab,
+ * complex<T>[N/nparts][rows][pitch]) -> fb_slab_pack -> ONE all-to-all of equal blocks (done by the
+ * caller: RCCL / torch.distributed) -> the receive buffer IS the kslab -> fb_slab_x_pass or the
+ * fused fb_slab_x_bin.  The inverse mirrors it: fb_slab_x_generate (or x_pass) -> all-to-all of the
+ * kslab's contiguous x-blocks -> fb_slab_unpack -> fb_slab_inverse_local (y pass + z c2r, 1/N^3).
+ * The noise of fb_slab_x_generate depends on global mode indices only: the field is the same for
+ * every nparts.  Cubic boxes only (shell amplitude / threshold tables).                          */
+int64_t fb_slab_half_bytes(const fb_plan* plan, int nparts);     /* x-slab half spectrum           */
+int64_t fb_slab_kspace_bytes(const fb_plan* plan, int nparts);   /* kslab = all-to-all buffer size  */
+int fb_slab_forward_local(fb_plan* plan, const void* real_local, void* half_local, int nparts, int pre_exp,
+                          double* expsum_dev, void* stream);
+int fb_slab_inverse_local(fb_plan* plan, void* half_local, void* real_local, int nparts, void* stream);
+int fb_slab_pack(fb_plan* plan, const void* half_local, void* sendbuf, int nparts, void* stream);
+int fb_slab_unpack(fb_plan* plan, const void* recvbuf, void* half_local, int nparts, void* stream);
+int fb_slab_x_pass(fb_plan* plan, void* kslab, int nparts, int direction, void* stream);
+int fb_slab_x_generate(fb_plan* plan, void* kslab, int nparts, int part, uint64_t seed, uint64_t realisation,
+                       void* stream);
+/* results_dev[2*nbins]: this rank's (sum |dk|^2, sum |dk|^4) per bin; all-reduce (sum) over ranks */
+int fb_slab_x_bin(fb_plan* plan, void* kslab, int nparts, int part, double* results_dev, void* stream);
+
 /* tuning aid: a single strided FFT pass over a half spectrum (axis 0 = x, 1 = y;
  * mode 0 plain in place, 1 fused generator, 2 fused binning without store) */
 int fb_debug_strided_pass(fb_plan* plan, void* half, int axis, int mode, void* stream);

@@ -1,0 +1,47 @@
+"""GPU: the slab-decomposed kernels (C ABI fb_slab_*) driven as P virtual ranks on one GPU must
+reproduce the single-GPU CosmoBox field and P(k) for every P (the exchange is emulated by block
+copies; the process-level exchange is covered by tests/test_slab_cpu.py under gloo)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("f64", 1e-11)])
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_virtual_ranks_match_single_gpu(P, precision, tol):
+    from fastbox_amd import CosmoBox, default_cosmo
+    from fastbox_amd.distributed import HipSlabOps, SlabBox, run_virtual
+    from fastbox_amd import hostgeom
+    N, L, seed = 64, 1e3, 77
+    ref = CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, precision=precision,
+                   rng="device", seed=seed)
+    want_dx = np.asarray(ref.realise_density())
+    want_pk = ref.binned_power_spectrum(delta_x=ref.delta_x, nbins=20)
+    want_ln = ref.binned_power_spectrum(delta_x=ref.lognormal(ref.delta_x), nbins=20)
+
+    boxes = [SlabBox(default_cosmo, box_scale=L, nsamp=N, precision=precision, seed=seed, rank=r, world=P,
+                     ops_factory=lambda g, PP, rr: HipSlabOps(g, PP, rr, precision=precision, device=0))
+             for r in range(P)]
+    reals = run_virtual(boxes, lambda b: b._gen_local(), lambda b, recv: b._gen_finish(recv))
+    dx = np.concatenate([r.double().cpu().numpy() for r in reals], axis=0)
+    assert np.max(np.abs(dx - want_dx)) < tol * np.std(want_dx)
+
+    for lognormal, want in ((False, want_pk), (True, want_ln)):
+        nb = 20
+        for b in boxes:
+            bins, kc = b._pk_setup(nb, None)
+        res = run_virtual(boxes, lambda b: b._pk_local(b.delta_x, lognormal, nb),
+                          lambda b, kslab: b._pk_finish(kslab, nb).clone())
+        h = sum(r.cpu().numpy() for r in res)
+        s1, s2, esum = h[0:2 * nb:2], h[1:2 * nb:2], h[2 * nb]
+        if lognormal:
+            mean = esum / float(N) ** 3
+            s1, s2 = s1 / mean ** 2, s2 / mean ** 4
+        pk, err = hostgeom.finish_bins(boxes[0].ops.bin_counts(), s1, s2, boxes[0].boxfactor)
+        assert np.array_equal(kc, want[0])
+        m = ~np.isnan(want[1])
+        assert np.array_equal(np.isnan(pk), np.isnan(want[1]))
+        ptol = 1e-5 if precision == "f32" else 1e-10
+        assert np.allclose(pk[m], want[1][m], rtol=ptol, atol=0)
+        assert np.all(np.abs(err[m] - want[2][m]) <= ptol * (np.abs(want[2][m]) + np.abs(want[1][m])))
