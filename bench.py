@@ -118,6 +118,18 @@ def main():
         alg_bytes = 2.0 * N * N * (N // 2 + 1) * 2 * s
         achieved = alg_bytes / (ms / max(launches, 1) * 1e-3) / 1e9 if ms > 0 else None
         total_ms = sum(v[0] for v in prof.values())
+        # HBM traffic of the same kernel from the PMC counters: collected off-line in two separate
+        # rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) over this very command and committed under
+        # profiles/; FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md (HBM).
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_summary.json")))
+            key = [k for k in pmc if "k_fft_strided<float, %d, 0" % N in k]
+            if key and args.precision == "f32":
+                c = pmc[key[0]]
+                traffic = (2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024.0
+        except Exception:
+            traffic = None
         line = {
             "metric": "%d^3 box realisations/sec (gen + log-normal + P(k))" % N,
             "value": world * args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps,
@@ -128,7 +140,8 @@ def main():
                        "nsamp": N, "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_fft_strided (x/y FFT pass, half spectrum)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
+                         "algorithmic_bytes": alg_bytes,
                          "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
             "kernel_ms_total_per_step": round(total_ms / args.steps, 4),
