@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--nbins", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nsamp", type=int, default=256)
+    ap.add_argument("--all-kernel-events", action="store_true",
+                    help="bracket every kernel with HIP events (per-kernel breakdown; costs ~4 %% of the rate); "
+                         "by default only the dominant kernel class is bracketed")
     return ap.parse_args()
 
 
@@ -95,7 +98,7 @@ def main():
     for _ in range(args.warmup):
         step().result()
     fence()
-    eng.profile_start()
+    eng.profile_start(None if args.all_kernel_events else ["fft_strided"])
     t0 = time.perf_counter()
     acc = np.zeros(args.nbins - 1)
     pending = [step() for _ in range(args.steps)]

@@ -328,6 +328,11 @@ int fb_debug_strided_pass(fb_plan* p, void* half, int axis, int mode, void* stre
     return FB_DISPATCH(p, fbi_debug_pass_f32(p, half, axis, mode, s), fbi_debug_pass_f64(p, half, axis, mode, s));
 }
 
+int fb_set_tuning(fb_plan* p, int stagger_plain, int stagger_gen, int stagger_bin) {
+    FB_REQUIRE(p, "null pointer");
+    p->stagger[0] = stagger_plain; p->stagger[1] = stagger_gen; p->stagger[2] = stagger_bin;
+    return FB_OK;
+}
 int fb_debug_read_stamps(fb_plan* p, long long* host, int64_t count) {
     FB_REQUIRE(p && host && p->bin_partials, "no stamps");
     FB_HIP(hipDeviceSynchronize());
@@ -335,6 +340,11 @@ int fb_debug_read_stamps(fb_plan* p, long long* host, int64_t count) {
     return FB_OK;
 }
 
+int fb_profile_select(fb_plan* p, unsigned mask) {
+    FB_REQUIRE(p, "null pointer");
+    p->prof_mask = mask;
+    return FB_OK;
+}
 int fb_profile_start(fb_plan* p) {
     FB_REQUIRE(p, "null pointer");
     p->prof_used = 0;

@@ -42,6 +42,8 @@ template <typename T> struct StridedArgs {
     T scale;
     int ntx;                 // tiles per outer index = ceil(ncols / TZ)      (set by the launcher)
     int ntiles;              // ntx * (number of outer indices)               (set by the launcher)
+    int stagger;             // first-generation workgroups [num_cu, 2 num_cu) sleep this many x64 cycles
+    int num_cu;
 };
 
 // operands of the fused modes (x pass of a half spectrum: line index = k_x,
@@ -82,9 +84,9 @@ __device__ __forceinline__ void wave_flush(int b, double s1, double s2, bool hav
 // the global loads of its next tile before transforming the current one, so that HBM requests
 // stay in flight through the LDS exchanges and the fused epilogue.
 // PERSIST = false: one tile per workgroup, two workgroups per CU (<= 64 VGPRs at 1024 threads).
-template <typename T, int N, int MODE, bool PERSIST>
+template <typename T, int N, int MODE, int PERSIST>   // 0: one tile per workgroup; 1: loop + register prefetch; 2: loop only
 __global__ __launch_bounds__(tile_cols<T>(N) * (N / strided_elems(N)),
-                             PERSIST ? 1 : fb_min(8, fb_max(1, 2 * tile_cols<T>(N) * (N / strided_elems(N)) / 256)))
+                             PERSIST == 1 ? 1 : fb_min(8, fb_max(1, 2 * tile_cols<T>(N) * (N / strided_elems(N)) / 256)))
 void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     constexpr int E = strided_elems(N);
     constexpr int TPL = N / E;
@@ -100,11 +102,23 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     const int tid = threadIdx.x;
     const int c = tid % TZ;
     const int t = tid / TZ;
-    for (int i = tid; i < N; i += NT) twl[i] = a.tw[i];
-    if constexpr (MODE == SMODE_BIN) {
-        for (int i = tid; i < NW * 2 * op.nbins; i += NT) acc[i] = 0.0;
-        for (int i = tid; i < op.nbins; i += NT) lthr[i] = op.thr[i];
-    }
+    // Two workgroups share a CU and, started together, stay in lockstep (same period): both wait
+    // for HBM, then both compute.  Delaying the second resident generation once by about half a
+    // period makes one compute while the other waits, for the whole launch.
+    if (a.stagger > 0 && (int)blockIdx.x >= a.num_cu && (int)blockIdx.x < 2 * a.num_cu)
+        for (int q = 0; q < a.stagger; q += 64) __builtin_amdgcn_s_sleep(64);
+    // The tables (twiddles; bin thresholds) are first needed after the first LDS exchange, whose
+    // barrier also publishes them: in the one-tile-per-workgroup form they are fetched AFTER the
+    // tile's own loads have been issued, and no barrier stands between a wave's loads and its
+    // first butterflies.
+    auto load_tables = [&]() {
+        for (int i = tid; i < N; i += NT) twl[i] = a.tw[i];
+        if constexpr (MODE == SMODE_BIN) {
+            for (int i = tid; i < NW * 2 * op.nbins; i += NT) acc[i] = 0.0;
+            for (int i = tid; i < op.nbins; i += NT) lthr[i] = op.thr[i];
+        }
+    };
+    if constexpr (PERSIST) load_tables();
     TileLayout<T, TZ> lay{tile, c};
 #ifdef FB_STAMPS      // diagnostic build only: phase time stamps of every workgroup (tools/stamps.py)
     long long* stamp = reinterpret_cast<long long*>(const_cast<double*>(op.bins)) + (size_t)blockIdx.x * 8;
@@ -122,7 +136,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     cx<T> v[E];
     [[maybe_unused]] cx<T> vn[E];
     int tile_id = blockIdx.x;
-    if constexpr (MODE != SMODE_GEN && PERSIST) {          // the launcher guarantees gridDim.x <= ntiles
+    if constexpr (MODE != SMODE_GEN && PERSIST == 1) {          // the launcher guarantees gridDim.x <= ntiles
         const int bx0 = tile_id % a.ntx;
         const cx<T>* src = a.in + ((long long)(tile_id / a.ntx) * a.outer_stride + bx0 * TZ);
         const unsigned voff = bx0 * TZ + c < a.ncols ? loff : FB_BUF_OOB;
@@ -179,7 +193,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     v[j + E / 2] = cx<T>{0, 0};
                 }
             }
-        } else if constexpr (!PERSIST) {
+        } else if constexpr (PERSIST != 1) {
             const cx<T>* src = a.in + ubase;
             const unsigned voff = valid ? loff : FB_BUF_OOB;
 #pragma unroll
@@ -203,7 +217,8 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FB_STAMP(2);
 #endif
-        __syncthreads();       // twiddles/thresholds visible; LDS of the previous tile's epilogue is free
+        if constexpr (PERSIST) __syncthreads();   // LDS of the previous tile's epilogue is free again
+        else load_tables();
         FB_STAMP(3);
         if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
         else if constexpr (MODE == SMODE_BIN) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);

@@ -17,6 +17,8 @@ struct fb_plan {
     int prec = 4;            // bytes per real: 4 (float) or 8 (double)
     double L[3] = {0, 0, 0};
     int device = 0;
+    int stagger[3] = {0, 0, 0};   // per strided-pass mode (plain, gen, bin), units of 64 cycles; fb_set_tuning
+    int debug_no_mem = 0;    // tuning aid (fb_debug_strided_pass mode >= 10)
     int num_cu = 256;        // compute units of the device (persistent-grid sizing)
     int NZV = 0;             // stored k_z modes of a half spectrum: N/2+1
     int NZP = 0;             // row pitch of a half spectrum (complex elements)
@@ -55,6 +57,7 @@ struct fb_plan {
 
     // per-kernel HIP-event timing (fb_profile_start / fb_profile_stop)
     bool prof_on = false;
+    unsigned prof_mask = 0xFFFFFFFFu;   // kernel classes to bracket (bit = FBK_* index)
     std::vector<hipEvent_t> prof_ev;   // pairs
     std::vector<int> prof_cat;
     size_t prof_used = 0;
@@ -67,7 +70,8 @@ enum { FBK_FFT_STRIDED = 0, FBK_FFT_CONTIG, FBK_COLOUR, FBK_BIN, FBK_FILTER, FBK
 // RAII: records an event pair around one launch while profiling is on
 struct FbProfScope {
     fb_plan* p; hipStream_t s; size_t slot; bool on;
-    FbProfScope(fb_plan* plan, int cat, hipStream_t stream) : p(plan), s(stream), slot(0), on(plan->prof_on) {
+    FbProfScope(fb_plan* plan, int cat, hipStream_t stream)
+        : p(plan), s(stream), slot(0), on(plan->prof_on && ((plan->prof_mask >> cat) & 1u)) {
         if (!on) return;
         if (p->prof_used + 2 > p->prof_ev.size()) {
             for (int q = 0; q < 64; ++q) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; }

@@ -358,7 +358,10 @@ class Engine(object):
     PROF_NAMES = ("fft_strided", "fft_contig", "colour", "bin", "filter", "velpot", "realop", "rsd", "layout",
                   "fft_gen", "fft_bin")
 
-    def profile_start(self):
+    def profile_start(self, only=None):
+        """Bracket kernel launches with HIP events; `only` = iterable of class names to restrict to."""
+        mask = 0xFFFFFFFF if only is None else sum(1 << self.PROF_NAMES.index(n) for n in only)
+        _lib.call("fb_profile_select", self._plan, mask)
         _lib.call("fb_profile_start", self._plan)
 
     def profile_stop(self):

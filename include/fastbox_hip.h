@@ -145,6 +145,7 @@ int fb_crop_full(fb_plan* plan, const void* full, void* half, void* stream);    
 #define FB_PROF_NCAT 11
 /* between start and stop every kernel launch of this plan is bracketed by an event pair;
  * stop synchronises and returns summed milliseconds and launch counts per class above.  */
+int fb_profile_select(fb_plan* plan, unsigned mask);   /* bit i = bracket class i; default all */
 int fb_profile_start(fb_plan* plan);
 int fb_profile_stop(fb_plan* plan, void* stream, double* ms, int64_t* launches, int ncat);
 
@@ -171,6 +172,9 @@ int fb_slab_x_generate(fb_plan* plan, void* kslab, int nparts, int part, uint64_
 /* results_dev[2*nbins]: this rank's (sum |dk|^2, sum |dk|^4) per bin; all-reduce (sum) over ranks */
 int fb_slab_x_bin(fb_plan* plan, void* kslab, int nparts, int part, double* results_dev, void* stream);
 
+/* start-up stagger of the second resident workgroup generation of the strided passes, in units of
+ * 64 shader cycles, per pass kind (0 = off); see k_fft_strided */
+int fb_set_tuning(fb_plan* plan, int stagger_plain, int stagger_gen, int stagger_bin);
 /* tuning aid: a single strided FFT pass over a half spectrum (axis 0 = x, 1 = y;
  * mode 0 plain in place, 1 fused generator, 2 fused binning without store) */
 int fb_debug_strided_pass(fb_plan* plan, void* half, int axis, int mode, void* stream);

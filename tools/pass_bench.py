@@ -13,8 +13,12 @@ dx = box.realise_density()
 box.binned_power_spectrum(delta_x=dx)            # sets bins/thresholds
 h = eng.empty(HALF)
 nbytes = 2.0 * N * N * (N // 2 + 1) * (8 if prec == "f32" else 16)
+stag = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+_lib.call("fb_set_tuning", eng._plan, stag, stag, stag)
+print("stagger", stag)
 for name, axis, mode, traffic in (("y plain", 1, 0, nbytes), ("x plain", 0, 0, nbytes), ("x gen  ", 0, 1, nbytes / 2),
-                                  ("x bin  ", 0, 2, nbytes / 2)):
+                                  ("x bin  ", 0, 2, nbytes / 2), ("y plain, no memory traffic", 1, 10, 0.0),
+                                  ("x gen,   no memory traffic", 0, 11, 0.0), ("x bin,   no memory traffic", 0, 12, 0.0)):
     for rep in range(2):
         eng.profile_start()
         for _ in range(10):
