@@ -50,6 +50,9 @@ SIGNATURES = {
     "fb_expand_half": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_crop_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_realise_density_device": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p, c_void_p]),
+    "fb_realise_density_begin": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p]),
+    "fb_realise_density_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fb_power_spectrum_pending": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "fb_power_spectrum_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fb_bin_counts": (c_int, [c_void_p, P_double]),
     "fb_slab_half_bytes": (c_i64, [c_void_p, c_int]),

@@ -97,6 +97,29 @@ class LognormalField(DeviceArray):
         return self._buf.ptr
 
 
+class PendingDensity(DeviceArray):
+    """delta_x of a device-RNG realisation whose last (z) FFT pass has not run yet.  Reading it
+    runs that pass; ``binned_power_spectrum(delta_x=...)`` of it (or of its log-normal) instead
+    fuses the pass with the power spectrum's first one, and fills in delta_x on the way."""
+
+    def __init__(self, engine, pending_half):
+        DeviceArray.__init__(self, engine, REAL, None)
+        self._pending = pending_half
+
+    @property
+    def materialised(self):
+        return self._buf is not None
+
+    def _adopt(self, real):
+        self._buf, self._pending = real._buf, None
+
+    @property
+    def ptr(self):
+        if self._buf is None:
+            self._adopt(self.engine.realise_finish(self._pending))
+        return self._buf.ptr
+
+
 class CosmoBox(object):
 
     def __init__(self, cosmo, box_scale=1e3, nsamp=32, redshift=0.,
@@ -261,8 +284,9 @@ class CosmoBox(object):
             del re, im
             delta_x = eng.fft_c2r(half, destroy=True)
         else:
-            # generator fused into the first inverse FFT pass (no coloured spectrum round trip)
-            delta_x = eng.realise_fused(self.seed, self._realisation)
+            # generator fused into the first inverse FFT pass (no coloured spectrum round trip); the
+            # last pass is deferred so that a following P(k) can fuse it with its own first pass
+            delta_x = PendingDensity(eng, eng.realise_begin(self.seed, self._realisation))
             self.last_realisation = self._realisation
             self._realisation += 1
         if inplace:
@@ -429,8 +453,12 @@ class CosmoBox(object):
             # fused path (cubic boxes): r2c with the binning inside the last pass
             ln = isinstance(delta_x, LognormalField) and not delta_x.materialised and bins[0] > 0.
             src = delta_x.source if ln else self._as_real(delta_x)
-            res, _ = eng.power_fused(src, pre_exp=ln)
-            pending = PendingSpectrum(eng, res, bins.size, kc, self.boxfactor, self.N ** 3 if ln else None, src)
+            if isinstance(src, PendingDensity) and not src.materialised:
+                res, real = eng.power_pending(src._pending, pre_exp=ln)     # z passes fused
+                src._adopt(real)
+            else:
+                res, _ = eng.power_fused(src, pre_exp=ln)
+            pending = PendingSpectrum(eng, res, bins.size, kc, self.boxfactor, self.N ** 3 if ln else None, None)
             return pending if not wait else pending.result()
 
         if delta_x is not None:

@@ -245,6 +245,27 @@ int fb_realise_density_device(fb_plan* p, uint64_t seed, uint64_t realisation, v
     return FB_DISPATCH(p, fbi_realise_fused_f32(p, seed, realisation, work_half, real_out, scale, s),
                        fbi_realise_fused_f64(p, seed, realisation, work_half, real_out, scale, s));
 }
+int fb_realise_density_begin(fb_plan* p, uint64_t seed, uint64_t realisation, void* pending_half, void* stream) {
+    FB_REQUIRE(p && pending_half, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_realise_begin_f32(p, seed, realisation, pending_half, s),
+                       fbi_realise_begin_f64(p, seed, realisation, pending_half, s));
+}
+int fb_realise_density_finish(fb_plan* p, void* pending_half, void* real_out, void* stream) {
+    FB_REQUIRE(p && pending_half && real_out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const double scale = 1.0 / ((double)p->N * p->N * p->N);
+    return FB_DISPATCH(p, fbi_realise_finish_f32(p, pending_half, real_out, scale, s),
+                       fbi_realise_finish_f64(p, pending_half, real_out, scale, s));
+}
+int fb_power_spectrum_pending(fb_plan* p, void* pending_half, void* real_out, int pre_exp, double* results_dev,
+                              void* stream) {
+    FB_REQUIRE(p && pending_half && real_out && results_dev, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const double scale = 1.0 / ((double)p->N * p->N * p->N);
+    return FB_DISPATCH(p, fbi_power_from_pending_f32(p, pending_half, real_out, scale, pre_exp, results_dev, s),
+                       fbi_power_from_pending_f64(p, pending_half, real_out, scale, pre_exp, results_dev, s));
+}
 int fb_power_spectrum_device(fb_plan* p, const void* real_in, void* work_half, int pre_exp, int keep_spectrum,
                              double* results_dev, void* stream) {
     FB_REQUIRE(p && real_in && work_half && results_dev, "null pointer");

@@ -361,7 +361,10 @@ static __global__ __launch_bounds__(256) void k_sum_columns(const double* __rest
     if (threadIdx.x == 0) out[q] = sh[0];
 }
 
-enum { ZMODE_C2C = 0, ZMODE_R2C = 1, ZMODE_C2R = 2 };
+enum { ZMODE_C2C = 0, ZMODE_R2C = 1, ZMODE_C2R = 2, ZMODE_C2R2C = 3 };
+// C2R2C: inverse z pass, write the real field, then (optionally exp() and) forward z pass of the
+// same line from registers: realise_density's last pass fused with the power spectrum's first,
+// so the real field is written once and never read back.
 
 template <typename T> struct ContigArgs {
     const void* in;
@@ -374,6 +377,7 @@ template <typename T> struct ContigArgs {
     T scale;
     int pre_exp;            // r2c: transform exp(x) instead of x (log-normal fusion)
     double* exp_partial;    // r2c + pre_exp: [gridDim.x] block sums of exp(x)
+    void* out2;             // C2R2C: half spectrum out (may alias `in`), pitch/skip as `in`
 };
 
 template <int NF> constexpr int contig_lines() {   // lines per workgroup
@@ -404,7 +408,7 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
     LineLayout<T> lay{lines + l * LP};
 
     cx<T> v[E];
-    if constexpr (MODE == ZMODE_C2R) {
+    if constexpr (MODE == ZMODE_C2R || MODE == ZMODE_C2R2C) {
         // Z[k] = (X[k] + conj X[n-k]) + i e^{+2 pi i k/N} (X[k] - conj X[n-k]); the
         // imaginary parts of X[0], X[n] are dropped (Hermitian projection).
         const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in) + (line + (a.in_skip ? line / a.in_skip : 0)) * a.in_pitch;
@@ -424,17 +428,20 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
         if (valid) {
             cx<T>* out = reinterpret_cast<cx<T>*>(reinterpret_cast<T*>(a.out) + line * a.out_pitch);
 #pragma unroll
-            for (int e = 0; e < E; ++e) out[t + e * TPL] = cscale(v[e], a.scale);
+            for (int e = 0; e < E; ++e) { v[e] = cscale(v[e], a.scale); out[t + e * TPL] = v[e]; }
         }
-    } else if constexpr (MODE == ZMODE_R2C) {
-        const cx<T>* in = reinterpret_cast<const cx<T>*>(reinterpret_cast<const T*>(a.in) + line * a.in_pitch);
+    }
+    if constexpr (MODE == ZMODE_R2C || MODE == ZMODE_C2R2C) {
         double esum = 0.0;
+        if constexpr (MODE == ZMODE_R2C) {
+            const cx<T>* in = reinterpret_cast<const cx<T>*>(reinterpret_cast<const T*>(a.in) + line * a.in_pitch);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (valid) {
-                v[e] = in[t + e * TPL];
-                if (a.pre_exp) { v[e].x = exp(v[e].x); v[e].y = exp(v[e].y); esum += (double)v[e].x + (double)v[e].y; }
-            } else v[e] = cx<T>{0, 0};
+            for (int e = 0; e < E; ++e) v[e] = valid ? in[t + e * TPL] : cx<T>{0, 0};
+        }
+        if (a.pre_exp) {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (valid) { v[e].x = exp(v[e].x); v[e].y = exp(v[e].y); esum += (double)v[e].x + (double)v[e].y; }
         }
         __syncthreads();
         fft_stages<T, NF, E, -1, TWS, 1>(v, t, twl, lay);
@@ -443,7 +450,10 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
         for (int e = 0; e < E; ++e) lay.at(t + e * TPL) = v[e];
         __syncthreads();
         if (valid) {
-            cx<T>* out = reinterpret_cast<cx<T>*>(a.out) + (line + (a.out_skip ? line / a.out_skip : 0)) * a.out_pitch;
+            cx<T>* out = (MODE == ZMODE_C2R2C)
+                ? reinterpret_cast<cx<T>*>(a.out2) + (line + (a.in_skip ? line / a.in_skip : 0)) * a.in_pitch
+                : reinterpret_cast<cx<T>*>(a.out) + (line + (a.out_skip ? line / a.out_skip : 0)) * a.out_pitch;
+            const T sc = (MODE == ZMODE_C2R2C) ? (T)1 : a.scale;     // C2R2C: `scale` belongs to the inverse half
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int k = t + e * TPL;
@@ -451,8 +461,8 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
                 cx<T> zn = cconj(lay.at((NF - k) & (NF - 1)));
                 cx<T> s = zk + zn, d = zk - zn;
                 cx<T> wd = cmul(twl[k], d);
-                out[k] = cx<T>{(T)0.5 * (s.x + wd.y) * a.scale, (T)0.5 * (s.y - wd.x) * a.scale};
-                if (k == 0) out[NF] = cx<T>{(zk.x - zk.y) * a.scale, (T)0};
+                out[k] = cx<T>{(T)0.5 * (s.x + wd.y) * sc, (T)0.5 * (s.y - wd.x) * sc};
+                if (k == 0) out[NF] = cx<T>{(zk.x - zk.y) * sc, (T)0};
             }
         }
         if (a.pre_exp) {                       // wave-uniform
@@ -467,7 +477,7 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
                 a.exp_partial[blockIdx.x] = s;
             }
         }
-    } else {
+    } else if constexpr (MODE == ZMODE_C2C) {
         const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in) + (line + (a.in_skip ? line / a.in_skip : 0)) * a.in_pitch;
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = valid ? in[t + e * TPL] : cx<T>{0, 0};

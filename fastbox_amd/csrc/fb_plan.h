@@ -117,6 +117,10 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_power_fused_##sfx(fb_plan* p, const void* real_in, void* work_half, int pre_exp, int store, \
                               double* results, hipStream_t s); \
     int fbi_debug_pass_##sfx(fb_plan* p, void* half, int axis, int mode, hipStream_t s); \
+    int fbi_realise_begin_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* work_half, hipStream_t s); \
+    int fbi_realise_finish_##sfx(fb_plan* p, void* work_half, void* real_out, double scale, hipStream_t s); \
+    int fbi_power_from_pending_##sfx(fb_plan* p, void* work_half, void* real_out, double scale, int pre_exp, \
+                                     double* results, hipStream_t s); \
     int fbi_slab_forward_local_##sfx(fb_plan* p, const void* real_local, void* half_local, int nxl, int pre_exp, \
                                      double* expsum, hipStream_t s); \
     int fbi_slab_inverse_local_##sfx(fb_plan* p, void* half_local, void* real_local, int nxl, double scale, hipStream_t s); \

@@ -96,6 +96,7 @@ class DeviceArray(NDArrayOperatorsMixin):
     @property
     def real(self):
         if self.kind == REAL:
+            self.ptr                            # materialise deferred fields
             return DeviceArray(self.engine, REAL, self._buf)
         return self.host().real
 
@@ -334,6 +335,26 @@ class Engine(object):
         _lib.call("fb_realise_density_device", self._plan, int(seed) & (2 ** 64 - 1),
                   int(realisation) & (2 ** 64 - 1), self._scratch_half().ptr, out.ptr, self.stream)
         return out
+
+    def realise_begin(self, seed, realisation):
+        """Generator + x and y passes; returns the pending half spectrum (z pass still to do)."""
+        pend = self.empty(HALF)
+        _lib.call("fb_realise_density_begin", self._plan, int(seed) & (2 ** 64 - 1),
+                  int(realisation) & (2 ** 64 - 1), pend.ptr, self.stream)
+        return pend
+
+    def realise_finish(self, pend):
+        out = self.empty(REAL)
+        _lib.call("fb_realise_density_finish", self._plan, pend.ptr, out.ptr, self.stream)
+        return out
+
+    def power_pending(self, pend, pre_exp=False):
+        """Fused z pass (writes delta_x) + P(k) of (exp of) it.  Returns (results buffer, delta_x)."""
+        res = self._alloc_bytes((2 * self._nbins + 1) * 8)
+        out = self.empty(REAL)
+        _lib.call("fb_power_spectrum_pending", self._plan, pend.ptr, out.ptr, 1 if pre_exp else 0, res.ptr,
+                  self.stream)
+        return res, out
 
     def power_fused(self, real, pre_exp=False, keep_spectrum=False):
         """Asynchronous r2c + shell binning (cubic boxes).  Returns (results buffer, spectrum or None);

@@ -81,6 +81,13 @@ int fb_colour_device(fb_plan* plan, uint64_t seed, uint64_t realisation, void* h
 int fb_realise_density_device(fb_plan* plan, uint64_t seed, uint64_t realisation, void* work_half,
                               void* real_out, void* stream);
 
+/* deferred form of the above: _begin runs the generator + x and y passes into `pending_half`
+ * (half-spectrum sized); the z pass is done later by _finish (real_out = delta_x), or by
+ * fb_power_spectrum_pending, which fuses it with the first pass of the power spectrum: real_out is
+ * written (delta_x is still produced) but never read back.                                      */
+int fb_realise_density_begin(fb_plan* plan, uint64_t seed, uint64_t realisation, void* pending_half, void* stream);
+int fb_realise_density_finish(fb_plan* plan, void* pending_half, void* real_out, void* stream);
+
 /* ---- binned power spectrum (binned_power_spectrum, box.py:741-764) ------------------------- */
 /* edges[nbins] as in np.digitize(k, edges).  thr/amb describe, for cubic boxes, the bin as a
  * step function of the integer shell (thr[b] = first n^2 with |k| >= edges[b]; amb = shells
@@ -98,6 +105,9 @@ int fb_bin_power(fb_plan* plan, const void* spec, int layout, double* count, dou
  * work_half is scratch and holds fftn(real_in) afterwards only if keep_spectrum.              */
 int fb_power_spectrum_device(fb_plan* plan, const void* real_in, void* work_half, int pre_exp,
                              int keep_spectrum, double* results_dev, void* stream);
+/* same results for a field still pending from fb_realise_density_begin (see there); consumes pending_half */
+int fb_power_spectrum_pending(fb_plan* plan, void* pending_half, void* real_out, int pre_exp, double* results_dev,
+                              void* stream);
 /* number of full-grid modes per bin for the current bin set (host array, nbins doubles) */
 int fb_bin_counts(fb_plan* plan, double* count);
 

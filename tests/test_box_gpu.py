@@ -284,3 +284,26 @@ def test_fused_binning_equals_unfused(precision, nbins):
     assert _pk_close(lazy[1:], mat[1:], 2e-5 if precision == "f32" else 1e-11)
     pend = box.binned_power_spectrum(delta_x=dx, nbins=nbins, wait=False)
     assert _pk_close(pend.result()[1:], box.binned_power_spectrum(delta_x=dx, nbins=nbins)[1:], 0)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("lognormal", [False, True])
+def test_deferred_realisation_fused_z_pass(precision, lognormal):
+    """rng='device': realise_density defers its last FFT pass; a following P(k) fuses that pass
+    with its own first one (and still delivers delta_x).  Must equal the unfused sequence."""
+    from fastbox_amd import CosmoBox, default_cosmo
+    kw = dict(cosmo=default_cosmo, box_scale=1e3, nsamp=64, realise_now=False, precision=precision,
+              rng="device", seed=4321)
+    a, b = CosmoBox(**kw), CosmoBox(**kw)
+    dxa = a.realise_density()
+    assert not dxa.materialised
+    fa = a.lognormal(dxa) if lognormal else dxa
+    pka = a.binned_power_spectrum(delta_x=fa, nbins=20)          # fused z passes
+    assert dxa.materialised
+    dxb = b.realise_density()
+    hb = np.asarray(dxb)                                         # plain z pass
+    fb_ = b.lognormal(dxb) if lognormal else dxb
+    pkb = b.binned_power_spectrum(delta_x=fb_, nbins=20)
+    tol = 2e-6 if precision == "f32" else 1e-12
+    assert np.max(np.abs(np.asarray(dxa) - hb)) <= tol * np.std(hb)
+    assert np.array_equal(pka[0], pkb[0]) and _pk_close(pka[1:], pkb[1:], 20 * tol)
