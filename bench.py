@@ -39,6 +39,11 @@ def parse():
     ap.add_argument("--nbins", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nsamp", type=int, default=256)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent realisations are issued round-robin on this many HIP streams (boxes), so that "
+                         "the compute-bound passes of one overlap the HBM-bound passes of the next (+8 %% at 2; "
+                         "default 1 so that per-kernel durations, and the roofline derived from them, are those of "
+                         "kernels running alone)")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="bracket every kernel with HIP events (per-kernel breakdown; costs ~4 %% of the rate); "
                          "by default only the dominant kernel class is bracketed")
@@ -81,11 +86,16 @@ def main():
     from fastbox_amd import CosmoBox, default_cosmo
 
     N = args.nsamp
-    box = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, redshift=0., realise_now=False,
-                   precision=args.precision, rng="device", seed=1000 + rank, device=local_rank)
-    eng = box.engine
+    from fastbox_amd.device import new_stream
+    boxes = [CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, redshift=0., realise_now=False,
+                      precision=args.precision, rng="device", seed=1000 * (rank + 1) + i, device=local_rank,
+                      stream=(new_stream() if args.streams > 1 else None)) for i in range(max(1, args.streams))]
+    eng = boxes[0].engine
+    counter = [0]
 
     def step():
+        box = boxes[counter[0] % len(boxes)]
+        counter[0] += 1
         dx = box.realise_density()
         return box.binned_power_spectrum(delta_x=box.lognormal(dx), nbins=args.nbins, wait=False)
 
@@ -95,8 +105,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, len(boxes))):
         step().result()
+    counter[0] = 0
     fence()
     eng.profile_start(None if args.all_kernel_events else ["fft_strided"])
     t0 = time.perf_counter()
@@ -140,7 +151,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "%d^3 Gaussian box (device Threefry noise, stand-in EH P(k), L=1000 Mpc) + "
                                    "log-normal transform + binned P(k), nbins=%d" % (N, args.nbins),
-                       "nsamp": N, "parallelism": "replicas x%d" % world},
+                       "nsamp": N, "parallelism": "replicas x%d" % world, "streams_per_gpu": len(boxes)},
             "roofline": {"bound": "hbm", "kernel": "k_fft_strided (x/y FFT pass, half spectrum)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,

@@ -413,6 +413,17 @@ int fb_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
     FB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return FB_OK;
 }
+int fb_stream_create(void** stream) {
+    FB_REQUIRE(stream, "null pointer");
+    hipStream_t s;
+    FB_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return FB_OK;
+}
+int fb_stream_destroy(void* stream) {
+    if (stream) FB_HIP(hipStreamDestroy((hipStream_t)stream));
+    return FB_OK;
+}
 int fb_stream_sync(void* stream) {
     FB_HIP(hipStreamSynchronize((hipStream_t)stream));
     return FB_OK;

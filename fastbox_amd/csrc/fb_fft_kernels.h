@@ -42,6 +42,7 @@ template <typename T> struct StridedArgs {
     T scale;
     int ntx;                 // tiles per outer index = ceil(ncols / TZ)      (set by the launcher)
     int ntiles;              // ntx * (number of outer indices)               (set by the launcher)
+    int drop_io;             // tuning aid: do all the arithmetic but no global loads/stores
     int stagger;             // first-generation workgroups [num_cu, 2 num_cu) sleep this many x64 cycles
     int num_cu;
 };
@@ -180,8 +181,12 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     T A0, A1;
                     if (op.amp.shell) {
                         const int mh = kx - (N >> 1);
+#ifdef FB_EXPERIMENT_NOAMP
+                        A0 = pf; A1 = pf * (T)(mh * mh + c2 > 0 ? 1 : 0);
+#else
                         A0 = op.amp.shell[kx * kx + c2] * pf;
                         A1 = op.amp.shell[mh * mh + c2] * pf;
+#endif
                     } else {
                         A0 = op.amp.dense[((long long)kx * op.g.NR + ky) * op.g.NZP + col] * pf;
                         A1 = op.amp.dense[((long long)(kx + (N >> 1)) * op.g.NR + ky) * op.g.NZP + col] * pf;
@@ -195,7 +200,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             }
         } else if constexpr (PERSIST != 1) {
             const cx<T>* src = a.in + ubase;
-            const unsigned voff = valid ? loff : FB_BUF_OOB;
+            const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = buf_load(make_rsrc(src + e * estep), voff, src);
         } else {
@@ -229,7 +234,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         FB_STAMP(4);
         if constexpr (MODE != SMODE_BIN) {
             cx<T>* dst = a.out + ubase;
-            const unsigned voff = valid ? loff : FB_BUF_OOB;
+            const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
 #pragma unroll
             for (int e = 0; e < E; ++e) buf_store(make_rsrc(dst + e * estep), voff, cscale(v[e], a.scale));
         }

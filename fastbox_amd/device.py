@@ -114,6 +114,15 @@ class DeviceArray(NDArrayOperatorsMixin):
         return "DeviceArray(kind=%s, shape=%s, precision=%s)" % (self.kind, self.shape, self.engine.precision)
 
 
+def new_stream():
+    """A fresh non-blocking HIP stream (raw handle) for ``CosmoBox(..., stream=...)``: independent
+    boxes on different streams overlap on the GPU (compute-bound passes of one with memory-bound
+    passes of the other)."""
+    s = ctypes.c_void_p()
+    _lib.call("fb_stream_create", ctypes.byref(s))
+    return s.value
+
+
 class Engine(object):
     """One fb_plan + buffer pool.  All field arguments are DeviceArrays."""
 
