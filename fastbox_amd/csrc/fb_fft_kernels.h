@@ -122,8 +122,11 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     if constexpr (PERSIST) load_tables();
     TileLayout<T, TZ> lay{tile, c};
 #ifdef FB_STAMPS      // diagnostic build only: phase time stamps of every workgroup (tools/stamps.py)
-    long long* stamp = reinterpret_cast<long long*>(const_cast<double*>(op.bins)) + (size_t)blockIdx.x * 8;
-#define FB_STAMP(k) do { if (tid == 0) stamp[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    long long* stamp = (MODE == SMODE_BIN)
+        ? reinterpret_cast<long long*>(op.partial + (size_t)2 * op.nbins * gridDim.x) + (size_t)blockIdx.x * 8
+        : reinterpret_cast<long long*>(const_cast<double*>(op.bins)) + (size_t)blockIdx.x * 8;
+    const bool stamp_ok = (MODE == SMODE_BIN) ? (op.partial != nullptr) : (op.bins != nullptr);
+#define FB_STAMP(k) do { if (tid == 0 && stamp_ok) stamp[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     FB_STAMP(0);
 #else
 #define FB_STAMP(k) do {} while (0)
@@ -248,37 +251,54 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 #pragma unroll
             for (int e = 0; e < E; ++e) ptile[(t + e * TPL) * TZ + c] = v[e].x * v[e].x + v[e].y * v[e].y;
             __syncthreads();
+            FB_STAMP(5);
             double* row = acc + (size_t)(tid >> 6) * 2 * nb;
             const int ky = by + op.outer0;             // global k_y (slab-decomposed runs own a k_y range)
             const int my = mode_of(ky, N);
             const int my2 = my * my;
             const int col0 = bx * TZ;
             const int off0 = tid * E;                      // lane's E consecutive elements
-            // Interior tiles (no k_z = 0 or N/2 column, no padding column: all but the first and
-            // last tile of a row) with the lane's elements inside one k_x row take a short path:
-            // every mode counts twice and n^2 is monotonic in k_z, so two threshold searches decide.
+            // Wave-level path.  A wave owns RW consecutive k_x rows x the tile's TZ columns, so the
+            // bounds of n^2 over its block are wave-uniform and the two threshold searches are done once
+            // per wave.  Almost always the block lies in one bin or straddles a single edge: each lane
+            // then splits its E modes at that edge, four wave reductions finish the job.  Weights: a
+            // stored mode counts twice except on the k_z = 0, N/2 planes; padding columns count 0.
             bool done = false;
-            if constexpr (TZ % E == 0) {
-                if (col0 > 0 && col0 + TZ <= (N >> 1)) {
+            if constexpr ((64 * E) % TZ == 0 && (N / 2) % ((64 * E) / TZ) == 0 && TZ % E == 0) {
+                constexpr int RW = (64 * E) / TZ;
+                const int r0 = __builtin_amdgcn_readfirstlane((tid >> 6) * RW);
+                const int ma = mode_of(r0, N), mb = mode_of(r0 + RW - 1, N);
+                const int a2 = ma * ma, b2 = mb * mb;
+                const int kzhi = (col0 + TZ - 1 < a.ncols - 1) ? col0 + TZ - 1 : a.ncols - 1;
+                const int wlo = (a2 < b2 ? a2 : b2) + my2 + col0 * col0;
+                const int whi = (a2 > b2 ? a2 : b2) + my2 + kzhi * kzhi;
+                const int blo = __builtin_amdgcn_readfirstlane(shell_bin(lthr, nb, wlo));
+                const int bhi = __builtin_amdgcn_readfirstlane(shell_bin(lthr, nb, whi));
+                bool hit = false;
+                for (int z = 0; z < op.namb; ++z) hit |= (op.amb[z] >= wlo && op.amb[z] <= whi);
+                if (!hit && bhi - blo <= 1) {
+                    const int edge = (bhi > blo) ? lthr[blo] : 0x7fffffff;       // first n^2 of bin bhi
                     const int mx = mode_of(off0 / TZ, N);
+                    const int n2row = mx * mx + my2;
                     const int kz0 = col0 + off0 % TZ;
-                    const int n2lo = mx * mx + my2 + kz0 * kz0;
-                    const int n2hi = mx * mx + my2 + (kz0 + E - 1) * (kz0 + E - 1);
-                    const int blo = shell_bin(lthr, nb, n2lo), bhi = shell_bin(lthr, nb, n2hi);
-                    bool hit = false;
-                    for (int z = 0; z < op.namb; ++z) hit |= (op.amb[z] >= n2lo && op.amb[z] <= n2hi);
-                    if (__all(blo == bhi && !hit)) {
-                        T s1 = 0;
-                        double s2 = 0.0;
+                    T s1 = 0, s2 = 0, u1 = 0, u2 = 0;
 #pragma unroll
-                        for (int q = 0; q < E; ++q) {
-                            const T p = ptile[off0 + q];
-                            s1 += p;
-                            s2 += (double)p * (double)p;
-                        }
-                        wave_flush(blo, 2.0 * (double)s1, 2.0 * s2, blo < nb, row);
-                        done = true;              // wave-uniform
+                    for (int q = 0; q < E; ++q) {
+                        const int kz = kz0 + q;
+                        T p = ptile[off0 + q];
+                        p = (kz >= a.ncols) ? (T)0 : ((kz == 0 || kz == (N >> 1)) ? p : (T)2 * p);   // weight in p
+                        const T p2 = (kz == 0 || kz == (N >> 1)) ? p * p : (T)0.5 * p * p;            // w p^2
+                        const bool up = n2row + kz * kz >= edge;
+                        s1 += up ? (T)0 : p; s2 += up ? (T)0 : p2;
+                        u1 += up ? p : (T)0; u2 += up ? p2 : (T)0;
                     }
+                    s1 = wave_sum(s1); s2 = wave_sum(s2);
+                    if (bhi > blo) { u1 = wave_sum(u1); u2 = wave_sum(u2); }
+                    if ((tid & 63) == 0) {
+                        if (blo < nb) { row[2 * blo] += (double)s1; row[2 * blo + 1] += (double)s2; }
+                        if (bhi > blo && bhi < nb) { row[2 * bhi] += (double)u1; row[2 * bhi + 1] += (double)u2; }
+                    }
+                    done = true;
                 }
             }
             if (!done) {
@@ -332,7 +352,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             }   // !done
         }
 #ifdef FB_STAMPS
-        FB_STAMP(5);
+        if constexpr (MODE != SMODE_BIN) FB_STAMP(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FB_STAMP(6);
 #endif
@@ -347,6 +367,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             for (int w2 = 0; w2 < NW; ++w2) sum += acc[(size_t)w2 * 2 * nb + i];
             op.partial[(size_t)i * gridDim.x + blockIdx.x] = sum;
         }
+        FB_STAMP(7);
     }
 }
 

@@ -8,22 +8,35 @@ from fastbox_amd.device import HALF
 
 N = 512
 axis = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 box = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False, precision="f32", rng="device")
 eng = box.engine
 h = eng.empty(HALF)
+dx = box.realise_density()
+box.binned_power_spectrum(delta_x=dx)            # sets bins/thresholds
 for _ in range(3):
-    _lib.call("fb_debug_strided_pass", eng._plan, h.ptr, axis, 0, eng.stream)
+    _lib.call("fb_debug_strided_pass", eng._plan, h.ptr, axis, mode, eng.stream)
 nt = 17 * N
-st = np.zeros((nt, 8), dtype=np.int64)
-_lib.call("fb_debug_read_stamps", eng._plan, st.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), st.size)
+if mode == 2:
+    raw = np.zeros(2 * 20 * nt + nt * 8, dtype=np.int64)
+    _lib.call("fb_debug_read_stamps", eng._plan, raw.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), raw.size)
+    st = raw[2 * 20 * nt:].reshape(nt, 8)
+else:
+    st = np.zeros((nt, 8), dtype=np.int64)
+    _lib.call("fb_debug_read_stamps", eng._plan, st.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), st.size)
 t0 = st[:, 0].min()
-names = ["start->loads issued", "loads issued->landed", "landed->barrier", "fft stages", "stores issued", "stores->drained"]
-d = np.diff(st[:, :7], axis=1).astype(float)
+names = ["start->loads issued", "loads issued->landed", "landed->tables", "fft stages",
+         "stores issued | p staged", "stores drained | binned", "(bin) partials written"]
+d = np.diff(st[:, :8], axis=1).astype(float)
 tick = 1.0  # report raw ticks and convert assuming 100 MHz
 print("workgroups", nt, "kernel span ticks", st[:, 6].max() - t0)
 for i, n in enumerate(names):
     print("%-24s median %8.0f  mean %8.0f  p90 %8.0f ticks" % (n, np.median(d[:, i]), d[:, i].mean(), np.percentile(d[:, i], 90)))
-life = (st[:, 6] - st[:, 0]).astype(float)
+life = (st[:, 7 if mode == 2 else 6] - st[:, 0]).astype(float)
+bx = np.arange(nt) % 17
+for k in (0, 1, 8, 16):
+    sel = bx == k
+    print("tiles with bx=%2d: median lifetime %8.0f, binning phase %8.0f" % (k, np.median(life[sel]), np.median(d[sel, 5])))
 print("workgroup lifetime       median %8.0f  mean %8.0f ticks" % (np.median(life), life.mean()))
 starts = np.sort(st[:, 0] - t0)
 print("start times: first 5", starts[:5], " 512th", starts[511], " 513th", starts[512], " last", starts[-1])
