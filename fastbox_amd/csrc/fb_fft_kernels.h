@@ -139,6 +139,8 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 
     cx<T> v[E];
     [[maybe_unused]] cx<T> vn[E];
+    [[maybe_unused]] int wb_lo = 0, wb_hi = 0, wb_edge = 0x7fffffff;   // BIN: this wave's bins (see epilogue)
+    [[maybe_unused]] bool wb_ok = false;
     int tile_id = blockIdx.x;
     if constexpr (MODE != SMODE_GEN && PERSIST == 1) {          // the launcher guarantees gridDim.x <= ntiles
         const int bx0 = tile_id % a.ntx;
@@ -227,6 +229,25 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 #endif
         if constexpr (PERSIST) __syncthreads();   // LDS of the previous tile's epilogue is free again
         else load_tables();
+        if constexpr (MODE == SMODE_BIN && (64 * E) % TZ == 0 && (N / 2) % ((64 * E) / TZ) == 0 && TZ % E == 0) {
+            // The bins of this wave's block of the tile depend on the tile's coordinates only: look
+            // them up now, with scalar loads from the global threshold table, while the tile's data
+            // is still on its way from HBM.
+            constexpr int RW = (64 * E) / TZ;
+            const int r0 = __builtin_amdgcn_readfirstlane((tid >> 6) * RW);
+            const int ma = mode_of(r0, N), mb = mode_of(r0 + RW - 1, N);
+            const int a2 = ma * ma, b2 = mb * mb;
+            const int myy = mode_of(by + op.outer0, N);
+            const int kzhi = (bx * TZ + TZ - 1 < a.ncols - 1) ? bx * TZ + TZ - 1 : a.ncols - 1;
+            const int wlo = (a2 < b2 ? a2 : b2) + myy * myy + bx * TZ * bx * TZ;
+            const int whi = (a2 > b2 ? a2 : b2) + myy * myy + kzhi * kzhi;
+            wb_lo = __builtin_amdgcn_readfirstlane(shell_bin(op.thr, op.nbins, wlo));
+            wb_hi = __builtin_amdgcn_readfirstlane(shell_bin(op.thr, op.nbins, whi));
+            bool hit = false;
+            for (int z = 0; z < op.namb; ++z) hit |= (op.amb[z] >= wlo && op.amb[z] <= whi);
+            wb_ok = !hit && wb_hi - wb_lo <= 1;
+            wb_edge = (wb_ok && wb_hi > wb_lo) ? op.thr[wb_lo] : 0x7fffffff;       // first n^2 of bin wb_hi
+        }
         FB_STAMP(3);
         if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
         else if constexpr (MODE == SMODE_BIN) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);
@@ -265,19 +286,8 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             // stored mode counts twice except on the k_z = 0, N/2 planes; padding columns count 0.
             bool done = false;
             if constexpr ((64 * E) % TZ == 0 && (N / 2) % ((64 * E) / TZ) == 0 && TZ % E == 0) {
-                constexpr int RW = (64 * E) / TZ;
-                const int r0 = __builtin_amdgcn_readfirstlane((tid >> 6) * RW);
-                const int ma = mode_of(r0, N), mb = mode_of(r0 + RW - 1, N);
-                const int a2 = ma * ma, b2 = mb * mb;
-                const int kzhi = (col0 + TZ - 1 < a.ncols - 1) ? col0 + TZ - 1 : a.ncols - 1;
-                const int wlo = (a2 < b2 ? a2 : b2) + my2 + col0 * col0;
-                const int whi = (a2 > b2 ? a2 : b2) + my2 + kzhi * kzhi;
-                const int blo = __builtin_amdgcn_readfirstlane(shell_bin(lthr, nb, wlo));
-                const int bhi = __builtin_amdgcn_readfirstlane(shell_bin(lthr, nb, whi));
-                bool hit = false;
-                for (int z = 0; z < op.namb; ++z) hit |= (op.amb[z] >= wlo && op.amb[z] <= whi);
-                if (!hit && bhi - blo <= 1) {
-                    const int edge = (bhi > blo) ? lthr[blo] : 0x7fffffff;       // first n^2 of bin bhi
+                const int blo = wb_lo, bhi = wb_hi, edge = wb_edge;
+                if (wb_ok) {
                     const int mx = mode_of(off0 / TZ, N);
                     const int n2row = mx * mx + my2;
                     const int kz0 = col0 + off0 % TZ;
