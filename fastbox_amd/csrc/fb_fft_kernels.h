@@ -386,8 +386,16 @@ static __global__ __launch_bounds__(256) void k_sum_columns(const double* __rest
                                                              int nvals, double* __restrict__ out) {
     __shared__ double sh[256];
     const int q = blockIdx.x;
-    double s = 0.0;
-    for (long long r = threadIdx.x; r < nrows; r += 256) s += partial[(size_t)q * nrows + r];
+    const double* src = partial + (size_t)q * nrows;
+    // fixed summation order (thread-strided, 8 independent chains so that the loads pipeline)
+    double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long r = threadIdx.x;
+    for (; r + 7 * 256 < nrows; r += 8 * 256) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] += src[r + u * 256];
+    }
+    for (int u = 0; r < nrows; r += 256, ++u) c[u & 7] += src[r];
+    const double s = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
