@@ -1,0 +1,108 @@
+"""GPU: edge cases of the reference interface and size-independent properties at BASELINE sizes."""
+import numpy as np
+import pytest
+
+from oracle import box_oracle as bo
+from oracle import standin
+
+pytestmark = pytest.mark.gpu
+
+
+def _box(N=32, L=5e2, **kw):
+    from fastbox_amd import CosmoBox, default_cosmo
+    return CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, **kw)
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-5), ("f64", 1e-11)])
+def test_host_arrays_and_non_hermitian_spectra(precision, tol):
+    """Host ndarrays go in as the reference accepts them: real fields, and arbitrary complex
+    (non-Hermitian) spectra, which take the full-layout kernels (binning, filter, velocity, c2c)."""
+    N, L = 32, 5e2
+    box = _box(N, L, precision=precision)
+    geo = bo.box_geometry(L, N)
+    rng = np.random.RandomState(2)
+    fk = rng.normal(size=(N, N, N)) + 1j * rng.normal(size=(N, N, N))
+    fx = rng.normal(size=(N, N, N))
+    got = box.binned_power_spectrum(delta_k=fk, nbins=15)
+    want = bo.binned_power_spectrum(geo, fk, nbins=15)
+    m = ~np.isnan(want[1])
+    assert np.array_equal(got[0], want[0]) and np.array_equal(np.isnan(got[1]), np.isnan(want[1]))
+    assert np.allclose(got[1][m], want[1][m], rtol=10 * tol) and np.allclose(got[2][m], want[2][m], rtol=10 * tol)
+    got = box.binned_power_spectrum(delta_x=fx, nbins=15)
+    want = bo.binned_power_spectrum(geo, np.fft.fftn(fx), nbins=15)
+    assert np.allclose(got[1][m], want[1][m], rtol=10 * tol)
+    out = np.asarray(box.apply_transfer_fn(fk, standin.beam_highpass))
+    want = bo.apply_transfer_fn(geo, fk, standin.beam_highpass)
+    assert np.max(np.abs(out - want)) < 10 * tol * np.std(want)
+    fac = standin.velocity_fac(standin.cosmology(), 1.0)
+    vel = box.realise_velocity(delta_k=fk)
+    wv = bo.realise_velocity(geo, fk, fac)
+    for c in range(3):
+        assert np.max(np.abs(np.asarray(vel[c]) - wv[c])) < 10 * tol * np.std(wv[c])
+    vel = box.realise_velocity(delta_x=fx)
+    wv = bo.realise_velocity(geo, np.fft.fftn(fx), fac)
+    assert np.max(np.abs(np.asarray(vel[2]) - wv[2])) < 10 * tol * np.std(wv[2])
+    phi = np.asarray(box.realise_potential(delta_k=fk))
+    assert np.max(np.abs(phi - bo.realise_potential(geo, fk))) < 10 * tol * np.std(phi)
+    with pytest.raises(ValueError):
+        box.realise_velocity(delta_x=fx, delta_k=fk)
+    with pytest.raises(ValueError):
+        box.binned_power_spectrum(delta_x=fx, delta_k=fk)
+
+
+def test_interface_errors_and_limits():
+    from fastbox_amd._lib import FastBoxError
+    box = _box()
+    with pytest.raises(FastBoxError):
+        _box(N=48)                                   # not a power of two: refused, no fallback
+    with pytest.raises(FastBoxError):
+        _box(N=8)
+    with pytest.raises(NotImplementedError):
+        box.redshift_space_density(delta_x=np.zeros((32,) * 3), velocity_z=np.zeros((32,) * 3), method="cubic")
+    with pytest.raises(ValueError):
+        box.binned_power_spectrum(delta_x=np.zeros((16,) * 3))      # wrong shape
+    with pytest.raises(AttributeError):
+        box.delta_k                                  # nothing realised yet, as in the reference
+    with pytest.raises(FastBoxError):
+        box.realise_density(); box.binned_power_spectrum(nbins=300)  # > 256 bins
+    # unsorted edges: np.digitize raises in the reference; here the device rejects them
+    with pytest.raises((FastBoxError, ValueError)):
+        box.binned_power_spectrum(kbins=np.array([0.3, 0.1, 0.2]))
+
+
+def test_empty_and_degenerate_bins():
+    """Bins beyond the Nyquist sphere are empty -> NaN (box.py uses N, not N/2, for kmax);
+    explicit edges starting at 0 keep the DC mode out of the fused log-normal path."""
+    np.random.seed(1)
+    box = _box(32, 5e2, precision="f64")
+    dx = box.realise_density()
+    kc, pk, err = box.binned_power_spectrum(nbins=20)
+    assert np.isnan(pk[-1]) and np.isnan(pk[-2]) and not np.isnan(pk[5])
+    geo = bo.box_geometry(5e2, 32)
+    kb = np.array([0.0, 0.02, 0.05, 0.1, 0.2])
+    ln = box.lognormal(dx)
+    got = box.binned_power_spectrum(delta_x=ln, kbins=kb)
+    want = bo.binned_power_spectrum(geo, np.fft.fftn(bo.lognormal(np.asarray(dx))), kbins=kb)
+    assert np.allclose(got[1], want[1], rtol=1e-9, equal_nan=True)
+
+
+@pytest.mark.parametrize("N", [512, 1024])
+def test_full_size_properties(N):
+    """Size-independent checks at the BASELINE sizes: Parseval, fused vs stand-alone binning,
+    reproducibility of the device generator, log-normal >= -1 and its mean."""
+    box = _box(N, 1e3, precision="f32", rng="device", seed=3)
+    dx = box.realise_density()
+    fused = box.binned_power_spectrum(delta_x=dx, nbins=20)        # fuses the z passes + binning
+    s1, s2 = box.test_parseval()
+    assert np.isclose(s1, s2, rtol=2e-5)
+    plain = box.binned_power_spectrum(nbins=20)                    # stored spectrum, stand-alone kernel
+    m = ~np.isnan(plain[1])
+    assert np.array_equal(np.isnan(fused[1]), np.isnan(plain[1]))
+    assert np.allclose(fused[1][m], plain[1][m], rtol=3e-6) and np.allclose(fused[2][m], plain[2][m], rtol=3e-5)
+    mean = box.engine.sum_real(dx) / float(N) ** 3
+    assert abs(mean) < 1e-3
+    ln = box.lognormal(dx)
+    total = box.engine.sum_real(ln) / float(N) ** 3
+    assert abs(total) < 1e-4                                       # <exp(d)/mean - 1> = 0
+    box2 = _box(N, 1e3, precision="f32", rng="device", seed=3)
+    assert box2.engine.sum_real(box2.realise_density(), squared=True) == box.engine.sum_real(dx, squared=True)
