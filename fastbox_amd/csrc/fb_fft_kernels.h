@@ -134,7 +134,11 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 
     // addressing: wave-uniform 64-bit tile/row base (scalar registers) + one 32-bit per-lane
     // element offset shared by all E rows, so the E loads/stores cost no address VGPRs
-    const unsigned loff = (unsigned)(((long long)t * a.stride + c) * (long long)sizeof(cx<T>));
+    // (the wave's first line index goes into the scalar base: at 2048^3 the x stride is 17-34 MB
+    // and t * stride would overflow the 32-bit lane offset)
+    const int t0 = __builtin_amdgcn_readfirstlane(t);
+    const long long tbase = (long long)t0 * a.stride;
+    const unsigned loff = (unsigned)(((long long)(t - t0) * a.stride + c) * (long long)sizeof(cx<T>));
     const long long estep = (long long)TPL * a.stride;
 
     cx<T> v[E];
@@ -144,7 +148,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     int tile_id = blockIdx.x;
     if constexpr (MODE != SMODE_GEN && PERSIST == 1) {          // the launcher guarantees gridDim.x <= ntiles
         const int bx0 = tile_id % a.ntx;
-        const cx<T>* src = a.in + ((long long)(tile_id / a.ntx) * a.outer_stride + bx0 * TZ);
+        const cx<T>* src = a.in + ((long long)(tile_id / a.ntx) * a.outer_stride + bx0 * TZ + tbase);
         const unsigned voff = bx0 * TZ + c < a.ncols ? loff : FB_BUF_OOB;
 #pragma unroll
         for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + e * estep), voff, src);
@@ -204,7 +208,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                 }
             }
         } else if constexpr (PERSIST != 1) {
-            const cx<T>* src = a.in + ubase;
+            const cx<T>* src = a.in + ubase + tbase;
             const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = buf_load(make_rsrc(src + e * estep), voff, src);
@@ -217,7 +221,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             // then waits for these loads before the current tile's first butterfly.
             const int nxt = tile_id + gridDim.x;
             const int nbx = nxt % a.ntx;
-            const cx<T>* src = a.in + ((long long)(nxt / a.ntx) * a.outer_stride + nbx * TZ);
+            const cx<T>* src = a.in + ((long long)(nxt / a.ntx) * a.outer_stride + nbx * TZ + tbase);
             const unsigned voff = (nxt < a.ntiles && nbx * TZ + c < a.ncols) ? loff : FB_BUF_OOB;
 #pragma unroll
             for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + e * estep), voff, src);
@@ -257,7 +261,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         }
         FB_STAMP(4);
         if constexpr (MODE != SMODE_BIN) {
-            cx<T>* dst = a.out + ubase;
+            cx<T>* dst = a.out + ubase + tbase;
             const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
 #pragma unroll
             for (int e = 0; e < E; ++e) buf_store(make_rsrc(dst + e * estep), voff, cscale(v[e], a.scale));
