@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--nbins", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nsamp", type=int, default=256)
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "slab"],
+                    help="replicas: every rank realises its own boxes (Monte-Carlo throughput, weak scaling; default). "
+                         "slab: ONE box of --nsamp^3 spread over the ranks, slab-decomposed FFT with one RCCL "
+                         "all-to-all per transform (strong scaling)")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent realisations are issued round-robin on this many HIP streams (boxes), so that "
                          "the compute-bound passes of one overlap the HBM-bound passes of the next (+8 %% at 2; "
@@ -86,6 +90,8 @@ def main():
     from fastbox_amd import CosmoBox, default_cosmo
 
     N = args.nsamp
+    if args.mode == "slab":
+        return slab_main(args, rank, world, local_rank, torch, dist, np)
     from fastbox_amd.device import new_stream
     boxes = [CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, redshift=0., realise_now=False,
                       precision=args.precision, rng="device", seed=1000 * (rank + 1) + i, device=local_rank,
@@ -163,6 +169,53 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_nsamp, args.nbins)
         print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def slab_main(args, rank, world, local_rank, torch, dist, np):
+    """One box over all ranks: SlabBox (x-slabs <-> k_y-slabs, one all-to-all per transform)."""
+    from fastbox_amd import default_cosmo
+    from fastbox_amd.distributed import SlabBox
+    N = args.nsamp
+    torch.cuda.set_device(local_rank)
+    box = SlabBox(default_cosmo, box_scale=1e3, nsamp=N, precision=args.precision, seed=1000, rank=rank, world=world,
+                  device=local_rank)
+
+    def step():
+        box.realise_density()
+        return box.binned_power_spectrum(nbins=args.nbins, lognormal=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kc, pk, err = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        s = 4 if args.precision == "f32" else 8
+        print(json.dumps({
+            "metric": "%d^3 box realisations/sec (gen + log-normal + P(k)), one box over all GPUs" % N,
+            "value": args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "%d^3 Gaussian box + log-normal + binned P(k), slab-decomposed FFT, one all-to-all "
+                                   "per transform, P(k) synchronised every step" % N, "nsamp": N,
+                       "parallelism": "slab x%d" % world,
+                       "all_to_all_bytes_per_rank_pair": (N // world) ** 2 * ((N // 2 + 16) // 16 * 16) * 2 * s},
+            "roofline": None, "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -114,6 +114,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libfastbox_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; "
                           "g.build()'` or `make -C fastbox_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7, and whichever copy is
+    # loaded first serves both.  torch initialised on top of /opt/rocm's copy reports "No HIP GPUs",
+    # so when torch is installed it goes first (it is needed anyway for the multi-GPU exchange).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

@@ -137,11 +137,30 @@ class SlabBox(object):
         self.delta_x = None
 
     # -- the single data-path collective --------------------------------------------------
+    def _host_staged(self, t):
+        """gloo has no device all-to-all: stage through the host (tests on a single GPU only)."""
+        return self.world > 1 and t.is_cuda and self._dist.get_backend(self.group) == "gloo"
+
     def _exchange(self, send, recv):
         if self.world == 1:
             recv.copy_(send)
+        elif self._host_staged(send):
+            h_in = send.detach().cpu().view(-1)
+            h_out = h_in.new_empty(h_in.shape)
+            self._dist.all_to_all_single(h_out, h_in, group=self.group)
+            recv.view(-1).copy_(h_out)
         else:
             self._dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+
+    def _all_reduce(self, t):
+        if self.world == 1:
+            return
+        if self._host_staged(t):
+            h = t.detach().cpu()
+            self._dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            self._dist.all_reduce(t, group=self.group)
 
     # -- realise_density (box.py:130-194, throughput mode) ------------------------------------
     def _gen_local(self):
@@ -192,8 +211,7 @@ class SlabBox(object):
         send = self._pk_local(real, lognormal, nb)
         self._exchange(send, self._kslab)
         res = self._pk_finish(self._kslab, nb)
-        if self.world > 1:
-            self._dist.all_reduce(res, group=self.group)          # 2*nbins+1 doubles
+        self._all_reduce(res)                                     # 2*nbins+1 doubles
         h = res.detach().cpu().numpy()
         s1, s2, esum = h[0:2 * nb:2].copy(), h[1:2 * nb:2].copy(), h[2 * nb]
         if lognormal:
