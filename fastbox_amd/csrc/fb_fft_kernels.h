@@ -15,15 +15,19 @@
 
 namespace fb {
 
+#ifndef FB_E16_FROM
+#define FB_E16_FROM 2048      // lines this long use 16 points per thread and a 128 KiB tile (one workgroup per CU): 2048^3 5.0 -> 7.8 boxes/s; at 1024 it loses (83 -> 77)
+#endif
 // elements per thread of the strided passes (16 = two radix-8 butterflies per stage was
 // measured slower on MI355X: 8 waves per CU cannot hide the LDS-exchange latency)
-constexpr int strided_elems(int n) { return fb_min(8, n); }
+constexpr int strided_elems(int n) { return n >= FB_E16_FROM ? 16 : fb_min(8, n); }
 
 // columns per tile of the strided pass: one 128-byte row segment, shrunk so the
 // tile stays within 64 KiB of LDS (two workgroups per CU), and widened for tiny grids so
 // that a workgroup is at least one full wave.
 template <typename T> constexpr int tile_cols(int n) {
-    return fb_max(fb_max(2, fb_min(128 / (2 * (int)sizeof(T)), 65536 / (n * 2 * (int)sizeof(T)))),
+    return fb_max(fb_max(2, fb_min(128 / (2 * (int)sizeof(T)),
+                                   (n >= FB_E16_FROM ? 131072 : 65536) / (n * 2 * (int)sizeof(T)))),
                   64 / (n / strided_elems(n)));
 }
 
@@ -87,7 +91,8 @@ __device__ __forceinline__ void wave_flush(int b, double s1, double s2, bool hav
 // PERSIST = false: one tile per workgroup, two workgroups per CU (<= 64 VGPRs at 1024 threads).
 template <typename T, int N, int MODE, int PERSIST>   // 0: one tile per workgroup; 1: loop + register prefetch; 2: loop only
 __global__ __launch_bounds__(tile_cols<T>(N) * (N / strided_elems(N)),
-                             PERSIST == 1 ? 1 : fb_min(8, fb_max(1, 2 * tile_cols<T>(N) * (N / strided_elems(N)) / 256)))
+                             PERSIST == 1 ? 1 : fb_min(8, fb_max(1, (N * tile_cols<T>(N) * 2 * (int)sizeof(T) > 81920 ? 1 : 2)
+                                                                     * tile_cols<T>(N) * (N / strided_elems(N)) / 256)))
 void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     constexpr int E = strided_elems(N);
     constexpr int TPL = N / E;
