@@ -33,6 +33,51 @@ template <int SIGN, typename T> __device__ __forceinline__ cx<T> mul_si(cx<T> a)
     if constexpr (SIGN > 0) return {-a.y, a.x}; else return {a.y, -a.x};
 }
 
+// ---- packed fp32 complex primitives -------------------------------------------------------
+// A complex float is a VGPR pair, and the VOP3P packed ops take per-half source selectors
+// (op_sel / op_sel_hi) and negations (neg_lo / neg_hi), so multiplying by +-i, complex products and
+// the w8 rotations need no register shuffles.  hipcc does not find these forms by itself (the plain
+// C++ below compiles to ~95 v_mov_b32 per 512-point line), hence the explicit instructions.
+typedef float fb_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fb_f2 to_f2(cx<float> a) { return __builtin_bit_cast(fb_f2, a); }
+__device__ __forceinline__ cx<float> to_cx(fb_f2 a) { return __builtin_bit_cast(cx<float>, a); }
+// a + SIGN i b
+template <int SIGN> __device__ __forceinline__ cx<float> pk_add_i(cx<float> a, cx<float> b) {
+    fb_f2 r;
+    if constexpr (SIGN > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(to_f2(a)), "v"(to_f2(b)));
+    else                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(to_f2(a)), "v"(to_f2(b)));
+    return to_cx(r);
+}
+// a * w (SIGN < 0) or a * conj(w) (SIGN > 0): tables hold forward twiddles
+template <int SIGN> __device__ __forceinline__ cx<float> pk_cmul(cx<float> a, cx<float> w) {
+    fb_f2 r;
+    if constexpr (SIGN < 0) {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(to_f2(a)), "v"(to_f2(w)));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(r) : "v"(to_f2(a)), "v"(to_f2(w)));
+    } else {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(to_f2(a)), "v"(to_f2(w)));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(r) : "v"(to_f2(a)), "v"(to_f2(w)));
+    }
+    return to_cx(r);
+}
+// a * exp(SIGN i pi/4) and a * exp(SIGN 3 i pi/4)
+template <int SIGN> __device__ __forceinline__ cx<float> pk_rot8(cx<float> a) {
+    const fb_f2 c = {0.70710678118654752440f, 0.70710678118654752440f};
+    fb_f2 t, r;   // SIGN<0: (x + y, y - x); SIGN>0: (x - y, y + x)
+    if constexpr (SIGN < 0) asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(t) : "v"(to_f2(a)));
+    else                    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(to_f2(a)));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(c));
+    return to_cx(r);
+}
+template <int SIGN> __device__ __forceinline__ cx<float> pk_rot83(cx<float> a) {
+    const fb_f2 c = {0.70710678118654752440f, 0.70710678118654752440f};
+    fb_f2 t, r;   // SIGN<0: (-x + y, -y - x); SIGN>0: (-x - y, -y + x)
+    if constexpr (SIGN < 0) asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,1]" : "=v"(t) : "v"(to_f2(a)));
+    else                    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(t) : "v"(to_f2(a)));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(c));
+    return to_cx(r);
+}
+
 // ---- small DFTs, natural-order output, w = exp(SIGN 2 pi i / R) ------------
 template <int SIGN, typename T> __device__ __forceinline__ void dft2(cx<T>& a, cx<T>& b) {
     cx<T> s = a + b; b = a - b; a = s;
@@ -56,6 +101,30 @@ template <int SIGN, typename T> __device__ __forceinline__ void dft8(cx<T>* u) {
     u[2] = a2 + b2; u[6] = a2 - b2;
     u[3] = a3 + b3; u[7] = a3 - b3;
 }
+// float: the same butterflies on the packed primitives (28 instructions for the radix-8 one)
+template <int SIGN>
+__device__ __forceinline__ void dft4(cx<float>& u0, cx<float>& u1, cx<float>& u2, cx<float>& u3) {
+    const cx<float> t0 = u0 + u2, t1 = u0 - u2, t2 = u1 + u3, d = u1 - u3;
+    u0 = t0 + t2; u2 = t0 - t2;
+    u1 = pk_add_i<SIGN>(t1, d); u3 = pk_add_i<-SIGN>(t1, d);
+}
+template <int SIGN> __device__ __forceinline__ void dft8(cx<float>* u) {
+    dft4<SIGN>(u[0], u[2], u[4], u[6]);
+    dft4<SIGN>(u[1], u[3], u[5], u[7]);
+    const cx<float> a0 = u[0], a1 = u[2], a2 = u[4], a3 = u[6];
+    const cx<float> b0 = u[1], b1 = pk_rot8<SIGN>(u[3]), b2 = u[5], b3 = pk_rot83<SIGN>(u[7]);
+    u[0] = a0 + b0; u[4] = a0 - b0;
+    u[1] = a1 + b1; u[5] = a1 - b1;
+    u[2] = pk_add_i<SIGN>(a2, b2); u[6] = pk_add_i<-SIGN>(a2, b2);
+    u[3] = a3 + b3; u[7] = a3 - b3;
+}
+// u * W (forward table entry w; the inverse transform uses its conjugate)
+template <int SIGN, typename T> __device__ __forceinline__ cx<T> twmul(cx<T> u, cx<T> w) {
+    if constexpr (SIGN > 0) w.y = -w.y;
+    return cmul(u, w);
+}
+template <int SIGN> __device__ __forceinline__ cx<float> twmul(cx<float> u, cx<float> w) { return pk_cmul<SIGN>(u, w); }
+
 template <int R, int SIGN, typename T> __device__ __forceinline__ void dft(cx<T>* u) {
     static_assert(R == 2 || R == 4 || R == 8, "radix");
     if constexpr (R == 2) dft2<SIGN>(u[0], u[1]);
@@ -128,9 +197,7 @@ __device__ __forceinline__ void fft_stages(cx<T> (&v)[E], const int t, const cx<
             const int k = (t + m * TPL) & (P - 1);
 #pragma unroll
             for (int q = 1; q < R; ++q) {
-                cx<T> w = tw[q * k * (N / (P * R)) * TWS];
-                if constexpr (SIGN > 0) w.y = -w.y;
-                u[q] = cmul(u[q], w);
+                u[q] = twmul<SIGN>(u[q], tw[q * k * (N / (P * R)) * TWS]);
             }
         }
         dft<R, SIGN>(u);
