@@ -166,8 +166,10 @@ def main():
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
             "kernel_ms_total_per_step": round(total_ms / args.steps, 4),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_nsamp, args.nbins)
+        else:
+            line["cpu_baseline"] = None
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
