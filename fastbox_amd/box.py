@@ -97,6 +97,22 @@ class LognormalField(DeviceArray):
         return self._buf.ptr
 
 
+class LazySpectrum(DeviceArray):
+    """A k-space field computed by `make()` on first use (e.g. one velocity component: callers of the
+    reference usually transform only v_z, box.py:285 returns all three)."""
+
+    def __init__(self, engine, kind, make):
+        DeviceArray.__init__(self, engine, kind, None)
+        self._make = make
+
+    @property
+    def ptr(self):
+        if self._buf is None:
+            self._buf = self._make()._buf
+            self._make = None
+        return self._buf.ptr
+
+
 class PendingDensity(DeviceArray):
     """delta_x of a device-RNG realisation whose last (z) FFT pass has not run yet.  Reading it
     runs that pass; ``binned_power_spectrum(delta_x=...)`` of it (or of its log-normal) instead
@@ -317,7 +333,8 @@ class CosmoBox(object):
             raise UnboundLocalError("local variable 'mx' referenced before assignment")
         fac = 100. * self.cosmo['h'] * _ccl.h_over_h0(self.cosmo, a=scale_factor) \
             * _ccl.growth_rate(self.cosmo, a=scale_factor) * scale_factor
-        velocity_k = tuple(self.engine.velocity_k(dk, c, fac) for c in range(3))
+        velocity_k = tuple(LazySpectrum(self.engine, dk.kind, lambda c=c: self.engine.velocity_k(dk, c, fac))
+                           for c in range(3))        # each component is computed when first used
         if inplace:
             self.velocity_k = velocity_k
         return velocity_k

@@ -425,13 +425,13 @@ __global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, con
     __syncthreads();
     for (int k = 2; k <= N; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int m = threadIdx.x; m < N; m += blockDim.x) {
-                const int p = m ^ j;
-                if (p > m) {
-                    const bool up = (m & k) == 0;
-                    const double a = key[m], b = key[p];
-                    if ((a > b) == up) { key[m] = b; key[p] = a; const double t = val[m]; val[m] = val[p]; val[p] = t; }
-                }
+            // one compare-exchange per thread and step: pair q -> (m, m | j) with bit j of m clear
+            for (int q = threadIdx.x; q < (N >> 1); q += blockDim.x) {
+                const int m = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+                const int p = m | j;
+                const bool up = (m & k) == 0;
+                const double a = key[m], b = key[p];
+                if ((a > b) == up) { key[m] = b; key[p] = a; const double t = val[m]; val[m] = val[p]; val[p] = t; }
             }
             __syncthreads();
         }
