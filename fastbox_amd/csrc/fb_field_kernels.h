@@ -459,4 +459,148 @@ __global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, con
     }
 }
 
+// ---- redshift-space remap without a sort (N >= 64) -----------------------------------------
+// np.interp on the sorted (s, delta) pairs only ever needs, for grid point z_c, the largest
+// s <= z_c and the smallest s > z_c.  With cell(s) = c for z_c <= s < z_{c+1}: the predecessor of
+// z_c is the maximum of the nearest non-empty cell below c, the successor the minimum of the
+// nearest non-empty cell at or above c, and an exact hit is min(cell c) == z_c.  So: per-cell
+// min / max by 64-bit LDS atomics on an order-preserving encoding of s, the values attached in a
+// second sweep, nearest non-empty cells by a wave scan.  One wavefront per line of sight, lane l
+// owns cells l*E .. l*E+E-1.  O(N) per line instead of the O(N log^2 N) sorting network of k_rsd.
+__device__ __forceinline__ unsigned long long order_bits(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double order_value(unsigned long long u) {
+    return __longlong_as_double((long long)((u >> 63) ? (u & 0x7fffffffffffffffull) : ~u));
+}
+// fmod(a, b) for b > 0: the correctly rounded quotient truncates to the true integer quotient or
+// one past it, a - q b is then exactly representable (fma), one conditional add repairs the latter.
+__device__ __forceinline__ double fmod_pos(double a, double b) {
+    const double q = trunc(a / b);
+    if (!(fabs(q) < 4.5e15)) return fmod(a, b);
+    double r = fma(-q, b, a);
+    if (a >= 0.0 ? r < 0.0 : r > 0.0) r += (a >= 0.0 ? b : -b);
+    return r;
+}
+
+constexpr int FB_RSD_WAVES = 4;
+
+template <typename T, int E>
+__global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
+        const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise, T* __restrict__ out,
+        const double* __restrict__ zgrid, double Hz, double sigma_nl, RngKey rkey) {
+    constexpr int N = E * 64;
+    typedef unsigned long long u64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double* zg = reinterpret_cast<double*>(smem);                                   // [N]       shared by the block
+    u64* kmx = reinterpret_cast<u64*>(smem) + N + w * 2 * N;                        // [N] per wave: max of cell
+    u64* kmn = kmx + N;                                                             // [N] per wave: min of cell
+    T* vmx = reinterpret_cast<T*>(smem + sizeof(double) * N * (1 + 2 * FB_RSD_WAVES)) + w * 2 * N;
+    T* vmn = vmx + N;
+    const long long los = (long long)blockIdx.x * FB_RSD_WAVES + w;                 // N*N % WAVES == 0
+    const T* d = delta + los * N;
+    const T* v = vz + los * N;
+    for (int m = threadIdx.x; m < N; m += 64 * FB_RSD_WAVES) zg[m] = zgrid[m];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { kmx[lane + 64 * e] = 0ull; kmn[lane + 64 * e] = ~0ull; }
+    __syncthreads();
+    const double zmin = zg[0], zmax = zg[N - 1];
+    const double len = zmax - zmin;
+    const double inv_dz = (double)(N - 1) / len;
+    u64 kb[E];
+    int cell[E];
+    T val[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+#pragma clang fp contract(off)
+        const int m = lane * E + e;
+        double vel = (double)v[m];
+        if (sigma_nl > 0.0) {
+            double n;
+            if (noise) n = (double)noise[los * N + m];
+            else {
+                const unsigned long long idx = (unsigned long long)los * N + m;
+                double g0, g1, g2, g3;
+                mode_noise_pair<double>(idx, 1u, rkey, g0, g1, g2, g3);
+                n = g0;
+            }
+            vel = vel + sigma_nl * n;
+        }
+        const double s = zg[m] - vel / Hz;
+        double r = fmod_pos(s - zmin, len);           // numpy % : result takes the divisor's sign
+        if (r != 0.0) { if (r < 0.0) r += len; } else r = 0.0;
+        const double key = r + zmin;
+        int c = (int)((key - zmin) * inv_dz);
+        c = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
+        for (int it = 0; it < N && c > 0 && key < zg[c]; ++it) --c;           // settle on z_c <= key < z_{c+1}
+        for (int it = 0; it < N && c < N - 1 && key >= zg[c + 1]; ++it) ++c;
+        kb[e] = order_bits(key);
+        cell[e] = c;
+        val[e] = d[m];
+        atomicMax(&kmx[c], kb[e]);
+        atomicMin(&kmn[c], kb[e]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (kmx[cell[e]] == kb[e]) vmx[cell[e]] = val[e];
+        if (kmn[cell[e]] == kb[e]) vmn[cell[e]] = val[e];
+    }
+    const double fill = 0.5 * ((double)d[0] + (double)d[N - 1]);
+    __syncthreads();
+    // nearest non-empty cell strictly below / at-or-above each of this lane's cells
+    u64 cmx[E], cmn[E];
+    int last = -1, first = N;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        cmx[e] = kmx[lane * E + e];
+        cmn[e] = kmn[lane * E + e];
+        if (cmx[e] != 0ull) { last = lane * E + e; if (first == N) first = lane * E + e; }
+    }
+    int below = last, above = first;                  // inclusive scans over lanes: max from the left, min from the right
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        const int b = __shfl_up(below, sft), a = __shfl_down(above, sft);
+        if (lane >= sft) below = b > below ? b : below;
+        if (lane + sft < 64) above = a < above ? a : above;
+    }
+    int run_below = __shfl_up(below, 1);              // exclusive: lanes to the left only
+    if (lane == 0) run_below = -1;
+    int nxt_above = __shfl_down(above, 1);
+    if (lane == 63) nxt_above = N;
+    int ab[E];
+    {
+        int a = nxt_above;
+#pragma unroll
+        for (int e = E - 1; e >= 0; --e) { if (cmx[e] != 0ull) a = lane * E + e; ab[e] = a; }
+    }
+    T y_out[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+#pragma clang fp contract(off)
+        const int c = lane * E + e;
+        const double x = zg[c];
+        const bool filled = cmx[e] != 0ull;
+        double y;
+        if (filled && order_value(cmn[e]) == x) y = (double)vmn[c];
+        else if (run_below < 0 || ab[e] >= N) y = fill;
+        else {
+            const double kj = order_value(kmx[run_below]), vj = (double)vmx[run_below];
+            const double kn = order_value(kmn[ab[e]]), vn = (double)vmn[ab[e]];
+            const double slope = (vn - vj) / (kn - kj);
+            y = slope * (x - kj) + vj;
+            if (y != y) {
+                y = slope * (x - kn) + vn;
+                if (y != y && vj == vn) y = vj;
+            }
+        }
+        y_out[e] = (T)y;
+        if (filled) run_below = c;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) out[los * N + lane * E + e] = y_out[e];
+}
+
 }  // namespace fb
