@@ -90,7 +90,7 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
 
 int fb_plan_destroy(fb_plan* p) {
     if (!p) return FB_OK;
-    void* ptrs[] = {p->tw, p->axis2, p->ksc, p->kpar, p->zgrid, p->amp_shell, p->bins, p->thr, p->counts,
+    void* ptrs[] = {p->tw, p->axis2, p->ksc, p->kpar, p->zgrid, p->amp_shell, p->amp_sym, p->bins, p->thr, p->counts,
                     p->partials, p->scratch, p->bin_partials, p->exp_partials};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     delete p;

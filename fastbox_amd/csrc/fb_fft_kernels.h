@@ -178,6 +178,11 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             const int my = mode_of(ky, N);
             const int c2 = my * my + col * col;            // col = k_z <= N/2 is its own mode number
             const T pf = plane_factor<T>(col, N);
+            // spread amplitude table: rows |m_x| = k_x and N/2 - k_x of plane |m_y|, this lane's k_z
+            const long long sym_step = (long long)TPL * ((N >> 1) + 1) * op.g.NZP;
+            const int amy = my < 0 ? -my : my;
+            const T* sym0 = op.amp.sym + ((long long)t * ((N >> 1) + 1) + amy) * op.g.NZP + col;
+            const T* sym1 = op.amp.sym + ((long long)((N >> 1) - t) * ((N >> 1) + 1) + amy) * op.g.NZP + col;
             uint32_t ctr[E / 2][4], rnd[E / 2][4];
 #pragma unroll
             for (int j = 0; j < E / 2; ++j) {
@@ -193,7 +198,10 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     box_muller(rnd[j][0], rnd[j][1], a0, a1);
                     box_muller(rnd[j][2], rnd[j][3], b0, b1);
                     T A0, A1;
-                    if (op.amp.shell) {
+                    if (op.amp.sym) {
+                        A0 = sym0[j * sym_step] * pf;
+                        A1 = sym1[-j * sym_step] * pf;
+                    } else if (op.amp.shell) {
                         const int mh = kx - (N >> 1);
 #ifdef FB_EXPERIMENT_NOAMP
                         A0 = pf; A1 = pf * (T)(mh * mh + c2 > 0 ? 1 : 0);
@@ -300,16 +308,35 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     const int mx = mode_of(off0 / TZ, N);
                     const int n2row = mx * mx + my2;
                     const int kz0 = col0 + off0 % TZ;
+                    // tiles away from the k_z = 0 and k_z >= N/2 columns: every mode is stored once
+                    // for itself and once for its mirror image (weight 2, applied after the sums)
+                    const bool inner = col0 > 0 && col0 + TZ <= (N >> 1);
                     T s1 = 0, s2 = 0, u1 = 0, u2 = 0;
+                    if (inner && bhi == blo) {                  // one bin, uniform weight: the common case
 #pragma unroll
-                    for (int q = 0; q < E; ++q) {
-                        const int kz = kz0 + q;
-                        T p = ptile[off0 + q];
-                        p = (kz >= a.ncols) ? (T)0 : ((kz == 0 || kz == (N >> 1)) ? p : (T)2 * p);   // weight in p
-                        const T p2 = (kz == 0 || kz == (N >> 1)) ? p * p : (T)0.5 * p * p;            // w p^2
-                        const bool up = n2row + kz * kz >= edge;
-                        s1 += up ? (T)0 : p; s2 += up ? (T)0 : p2;
-                        u1 += up ? p : (T)0; u2 += up ? p2 : (T)0;
+                        for (int q = 0; q < E; ++q) { const T p = ptile[off0 + q]; s1 += p; s2 += p * p; }
+                        s1 *= (T)2; s2 *= (T)2;
+                    } else if (inner) {
+#pragma unroll
+                        for (int q = 0; q < E; ++q) {
+                            const int kz = kz0 + q;
+                            const T p = ptile[off0 + q], p2 = p * p;
+                            const bool up = n2row + kz * kz >= edge;
+                            s1 += up ? (T)0 : p; s2 += up ? (T)0 : p2;
+                            u1 += up ? p : (T)0; u2 += up ? p2 : (T)0;
+                        }
+                        s1 *= (T)2; s2 *= (T)2; u1 *= (T)2; u2 *= (T)2;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < E; ++q) {
+                            const int kz = kz0 + q;
+                            T p = ptile[off0 + q];
+                            p = (kz >= a.ncols) ? (T)0 : ((kz == 0 || kz == (N >> 1)) ? p : (T)2 * p);   // weight in p
+                            const T p2 = (kz == 0 || kz == (N >> 1)) ? p * p : (T)0.5 * p * p;            // w p^2
+                            const bool up = n2row + kz * kz >= edge;
+                            s1 += up ? (T)0 : p; s2 += up ? (T)0 : p2;
+                            u1 += up ? p : (T)0; u2 += up ? p2 : (T)0;
+                        }
                     }
                     s1 = wave_sum(s1); s2 = wave_sum(s2);
                     if (bhi > blo) { u1 = wave_sum(u1); u2 = wave_sum(u2); }

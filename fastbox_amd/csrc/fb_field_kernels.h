@@ -62,7 +62,20 @@ template <typename T> __device__ __forceinline__ T nan_to_num(T v) {   // np.nan
 template <typename T> struct AmpSrc {
     const T* shell;   // [n^2] for cubic boxes, or
     const T* dense;   // [N][N][NZP] evaluated per stored mode on the host
+    const T* sym;     // [N/2+1][N/2+1][NZP] = shell[a^2 + b^2 + c^2]: the shell table spread over
+                      // (|m_x|, |m_y|, k_z) so that the fused generator reads it in k_z-contiguous runs
 };
+// A 64-lane gather from the n^2-indexed shell table touches ~64 cache lines (neighbouring k_z are
+// 2 k_z + 1 entries apart) and costs the generator pass more than its random numbers; the spread
+// table is read like the data itself, 16 consecutive k_z per row.  Built once per amplitude table.
+template <typename T>
+__global__ void k_build_amp_sym(const T* __restrict__ shell, T* __restrict__ sym, int N, int NZP) {
+    const int M = (N >> 1) + 1;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y, a = blockIdx.z;
+    if (c >= NZP) return;
+    sym[((long long)a * M + b) * NZP + c] = c < M ? shell[a * a + b * b + c * c] : (T)0;
+}
 template <typename T>
 __device__ __forceinline__ T amp_at(const AmpSrc<T>& a, const KGeom& g, int i, int j, int l) {
     if (a.shell) return a.shell[shell_of(i, j, l, g.N)];
@@ -215,10 +228,20 @@ static __global__ void k_bin_count(unsigned long long* __restrict__ counts, KGeo
 }
 
 // ---- reductions ---------------------------------------------------------------------------------
+// Sum over the 64 lanes, returned in every lane.  float: six DPP adds (row_shr 1, 2, 4, 8, then
+// row_bcast 15 and 31 carry the row totals forward; lanes a step does not reach add the `old`
+// operand 0), total in lane 63, one v_readlane -- no LDS crossbar round trips.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+#define FB_DPP_ADD(ctrl, rmask, bmask) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, bmask, false))
+    FB_DPP_ADD(0x111, 0xf, 0xf);     // row_shr:1
+    FB_DPP_ADD(0x112, 0xf, 0xf);     // row_shr:2
+    FB_DPP_ADD(0x114, 0xf, 0xe);     // row_shr:4, lanes 4..15 of each row
+    FB_DPP_ADD(0x118, 0xf, 0xc);     // row_shr:8, lanes 8..15 of each row
+    FB_DPP_ADD(0x142, 0xa, 0xf);     // row_bcast:15 into rows 1 and 3
+    FB_DPP_ADD(0x143, 0xc, 0xf);     // row_bcast:31 into rows 2 and 3
+#undef FB_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

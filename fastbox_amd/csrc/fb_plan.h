@@ -35,6 +35,7 @@ struct fb_plan {
     void* amp_shell = nullptr;   // [nshell] plan precision, index n^2 = i^2+j^2+l^2 (cubic only)
     int64_t nshell = 0;
     const void* amp_dense = nullptr;  // caller-owned [N][N][NZP]
+    void* amp_sym = nullptr;     // [N/2+1][N/2+1][NZP] plan precision: amp_shell spread over (|m_x|, |m_y|, k_z)
 
     // P(k) binning (box.py:745-764)
     double* bins = nullptr;      // [nbins] edges

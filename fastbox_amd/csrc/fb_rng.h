@@ -83,9 +83,13 @@ __device__ __forceinline__ void threefry4x32_20_batch(const uint32_t (&ctr)[B][4
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& g0, float& g1) {
     const float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;
     const float u2 = ((float)b + 0.5f) * 2.3283064365386963e-10f;
+#ifdef FB_EXPERIMENT_NOBM     // knock-out build (tools/knockout.sh): no transcendentals
+    g0 = u1; g1 = u2;
+#else
     const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // -2 ln2 log2(u1)
     g0 = r * __builtin_amdgcn_cosf(u2);
     g1 = r * __builtin_amdgcn_sinf(u2);
+#endif
 }
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, double& g0, double& g1) {
     const double u1 = ((double)a + 0.5) * 2.3283064365386963e-10;

@@ -137,6 +137,22 @@ def test_redshift_space_fp64(golden_dir, name):
     assert _pk_close((pk,), (g["pkrsd_p"],), 1e-9)
 
 
+@pytest.mark.parametrize("N,vscale", [(128, 0.), (128, 40.), (256, 3e4)])
+def test_redshift_space_cells_per_lane(N, vscale):
+    """Several cells per lane (E = N/64 > 1) of the sort-free remap: all exact hits (v = 0),
+    sub-cell shifts (mostly one key per cell), and many wraps with empty / crowded cells."""
+    from fastbox_amd import CosmoBox, default_cosmo
+    rng = np.random.RandomState(5)
+    box = CosmoBox(cosmo=default_cosmo, box_scale=3e2, nsamp=N, realise_now=False, precision="f64")
+    geo = bo.box_geometry(3e2, N)
+    d = rng.normal(size=(N, N, N))
+    v = vscale * rng.normal(size=(N, N, N))
+    Hz = standin.hubble(standin.cosmology(), 1.0)
+    want = bo.redshift_space_density(geo, d, v, Hz, 0.)
+    got = np.asarray(box.redshift_space_density(delta_x=d, velocity_z=v, sigma_nl=0.))
+    assert np.max(np.abs(got - want)) < 1e-12 * np.max(np.abs(want))
+
+
 @pytest.mark.parametrize("N", [16, 64])
 def test_redshift_space_kernel_exact_on_same_inputs(N):
     """Given identical (fp64) inputs the device remap must equal the oracle's restatement of
