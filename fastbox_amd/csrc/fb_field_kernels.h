@@ -301,7 +301,8 @@ struct FilterSpec {
 // WEDGE       : 0 where |kpar| < p0 * kperp + p1, else 1
 // TOPHAT      : 3 (sin x - x cos x)/x^3, x = |k| p0   (NaN at k=0 -> 0 after nan_to_num)
 template <typename T>
-__device__ __forceinline__ T filter_value(const FilterSpec& f, const KGeom& g, int i, int j, int l, long long idx) {
+__device__ __forceinline__ T filter_value(const FilterSpec& f, const KGeom& g, int i, int j, int l, long long idx,
+                                          double kperp_row) {
     if (f.kind == FILT_TABLE) return reinterpret_cast<const T*>(f.table)[idx];
     if (f.kind == FILT_TOPHAT) {
         const T x = (T)(kmag_exact(g, i, j, l) * f.p[0]);
@@ -309,7 +310,7 @@ __device__ __forceinline__ T filter_value(const FilterSpec& f, const KGeom& g, i
         fb_sincos(x, &s, &c);
         return ((T)3 / (x * x * x)) * (s - x * c);
     }
-    const T kperp = (T)kperp_exact(g, i, j);
+    const T kperp = (T)kperp_row;
     const T kpar = (T)g.kpar[l];
     if (f.kind == FILT_WEDGE) return (fabs(kpar) < (T)f.p[0] * kperp + (T)f.p[1]) ? (T)0 : (T)1;
     T v = (T)1;
@@ -321,54 +322,86 @@ __device__ __forceinline__ T filter_value(const FilterSpec& f, const KGeom& g, i
     if (f.p[1] > 0) { const T r = kperp / (T)f.p[1]; v *= exp((T)-0.5 * r * r); }
     return v;
 }
+// The k-space pointwise kernels below run one (k_x, k_y) row per group of 64 lanes (blockDim =
+// (64, FB_ROW_GROUPS)); a lane walks k_z = lane, lane + 64, ...  Row constants (k_perp, the
+// k_x^2 + k_y^2 part of k^2) are computed once per lane instead of once per mode.
+#define FB_ROW_GROUPS 4
 // out = nan_to_num(in * T(k)); pitch = NZP (half) or N (full); nz = stored k_z count
 template <typename T>
-__global__ void k_apply_filter(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, FilterSpec f, KGeom g,
-                               int pitch, int nz) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y, i = blockIdx.z;
-    if (l >= nz) return;
-    const long long idx = ((long long)i * (nz == g.NZV ? g.NR : g.N) + j) * pitch + l;
-    const T m = filter_value<T>(f, g, i, j, l, idx);
-    const cx<T> d = in[idx];
-    out[idx] = cx<T>{nan_to_num(d.x * m), nan_to_num(d.y * m)};
+__global__ __launch_bounds__(64 * FB_ROW_GROUPS)
+void k_apply_filter(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, FilterSpec f, KGeom g, int pitch, int nz) {
+    const long long row = (long long)blockIdx.x * FB_ROW_GROUPS + threadIdx.y;
+    if (row >= (long long)g.N * g.N) return;
+    const int i = (int)(row / g.N), j = (int)(row % g.N);
+    const long long base = ((long long)i * (nz == g.NZV ? g.NR : g.N) + j) * pitch;
+    const double kperp = kperp_exact(g, i, j);
+    for (int l = threadIdx.x; l < nz; l += 64) {
+        const T m = filter_value<T>(f, g, i, j, l, base + l, kperp);
+        const cx<T> d = in[base + l];
+        out[base + l] = cx<T>{nan_to_num(d.x * m), nan_to_num(d.y * m)};
+    }
 }
 
 // ---- velocity / potential ------------------------------------------------------------------------------
 // box.py:251-284: A_c = i delta_k k_c / k^2, NaN -> 0, plane m_c = -N/2 zeroed, times fac.
+// fp64 plans follow the reference's operation order (k = 2 pi sqrt(.), k^2 = k k, two divisions);
+// fp32 plans form k_c fac / k^2 once per mode with a single-precision division (3e-7 relative).
 template <typename T>
-__global__ void k_velocity(const cx<T>* __restrict__ dk, cx<T>* __restrict__ out, KGeom g, int comp, double fac,
-                           int pitch, int nz) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y, i = blockIdx.z;
-    if (l >= nz) return;
-    const long long idx = ((long long)i * (nz == g.NZV ? g.NR : g.N) + j) * pitch + l;
-    const int ic = comp == 0 ? i : (comp == 1 ? j : l);
-    const double k = kmag_exact(g, i, j, l);
-    const double k2 = k * k;
-    const cx<T> d = dk[idx];
-    cx<T> v{0, 0};
-    if (k2 > 0.0 && ic != (g.N >> 1)) {
-        const double kc = g.ksc[comp * g.N + ic];
-        // (i d) * kc / k2  with i d = (-d.y, d.x)
-        v.x = (T)(((double)(-d.y) * kc) / k2 * fac);
-        v.y = (T)(((double)d.x * kc) / k2 * fac);
+__global__ __launch_bounds__(64 * FB_ROW_GROUPS)
+void k_velocity(const cx<T>* __restrict__ dk, cx<T>* __restrict__ out, KGeom g, int comp, double fac, int pitch, int nz) {
+    const long long row = (long long)blockIdx.x * FB_ROW_GROUPS + threadIdx.y;
+    if (row >= (long long)g.N * g.N) return;
+    const int i = (int)(row / g.N), j = (int)(row % g.N);
+    const long long base = ((long long)i * (nz == g.NZV ? g.NR : g.N) + j) * pitch;
+    const double rowsum = g.axis2[i] + g.axis2[g.N + j];
+    for (int l = threadIdx.x; l < nz; l += 64) {
+#pragma clang fp contract(off)
+        const int ic = comp == 0 ? i : (comp == 1 ? j : l);
+        const double s2 = rowsum + g.axis2[2 * g.N + l];
+        const cx<T> d = dk[base + l];
+        cx<T> v{0, 0};
+        if (s2 > 0.0 && ic != (g.N >> 1)) {
+            const double kc = g.ksc[comp * g.N + ic];
+            if constexpr (sizeof(T) == 4) {
+                const float m = (float)(kc * fac) / (float)((FB_TWO_PI * FB_TWO_PI) * s2);
+                v.x = -d.y * m;
+                v.y = d.x * m;
+            } else {
+                const double k = FB_TWO_PI * sqrt(s2);
+                const double k2 = k * k;
+                // (i d) * kc / k2  with i d = (-d.y, d.x)
+                v.x = (T)(((double)(-d.y) * kc) / k2 * fac);
+                v.y = (T)(((double)d.x * kc) / k2 * fac);
+            }
+        }
+        out[base + l] = v;
     }
-    out[idx] = v;
 }
 // box.py:347-348
 template <typename T>
-__global__ void k_potential(const cx<T>* __restrict__ dk, cx<T>* __restrict__ out, KGeom g, int pitch, int nz) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y, i = blockIdx.z;
-    if (l >= nz) return;
-    const long long idx = ((long long)i * (nz == g.NZV ? g.NR : g.N) + j) * pitch + l;
-    const double k = kmag_exact(g, i, j, l);
-    const double k2 = k * k;
-    const cx<T> d = dk[idx];
-    cx<T> v{0, 0};
-    if (i | j | l) { v.x = (T)((double)d.x / k2); v.y = (T)((double)d.y / k2); }
-    out[idx] = v;
+__global__ __launch_bounds__(64 * FB_ROW_GROUPS)
+void k_potential(const cx<T>* __restrict__ dk, cx<T>* __restrict__ out, KGeom g, int pitch, int nz) {
+    const long long row = (long long)blockIdx.x * FB_ROW_GROUPS + threadIdx.y;
+    if (row >= (long long)g.N * g.N) return;
+    const int i = (int)(row / g.N), j = (int)(row % g.N);
+    const long long base = ((long long)i * (nz == g.NZV ? g.NR : g.N) + j) * pitch;
+    const double rowsum = g.axis2[i] + g.axis2[g.N + j];
+    for (int l = threadIdx.x; l < nz; l += 64) {
+#pragma clang fp contract(off)
+        const cx<T> d = dk[base + l];
+        cx<T> v{0, 0};
+        if (i | j | l) {
+            if constexpr (sizeof(T) == 4) {
+                const float r = 1.0f / (float)((FB_TWO_PI * FB_TWO_PI) * (rowsum + g.axis2[2 * g.N + l]));
+                v.x = d.x * r; v.y = d.y * r;
+            } else {
+                const double k = FB_TWO_PI * sqrt(rowsum + g.axis2[2 * g.N + l]);
+                const double k2 = k * k;
+                v.x = (T)((double)d.x / k2); v.y = (T)((double)d.y / k2);
+            }
+        }
+        out[base + l] = v;
+    }
 }
 
 // ---- layout helpers ----------------------------------------------------------------------------------------
@@ -431,12 +464,7 @@ __global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, con
         if (sigma_nl > 0.0) {
             double n;
             if (noise) n = (double)noise[los * N + m];
-            else {
-                const unsigned long long idx = (unsigned long long)los * N + m;
-                double g0, g1, g2, g3;
-                mode_noise_pair<double>(idx, 1u, rkey, g0, g1, g2, g3);
-                n = g0;
-            }
+            else n = (double)los_noise_at<T>((unsigned long long)los * N + m, rkey);
             vel = vel + sigma_nl * n;
         }
         double s = zgrid[m] - vel / Hz;
@@ -535,22 +563,27 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
     u64 kb[E];
     int cell[E];
     T val[E];
+    T nz[E];
+    if (sigma_nl > 0.0) {
+        const unsigned long long idx0 = (unsigned long long)los * N + lane * E;
+        if (noise) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) nz[e] = noise[idx0 + e];
+        } else if constexpr (E % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < E / 4; ++q)
+                mode_noise_pair<T>((idx0 >> 2) + q, 1u, rkey, nz[4 * q], nz[4 * q + 1], nz[4 * q + 2], nz[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) nz[e] = los_noise_at<T>(idx0 + e, rkey);
+        }
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
 #pragma clang fp contract(off)
         const int m = lane * E + e;
         double vel = (double)v[m];
-        if (sigma_nl > 0.0) {
-            double n;
-            if (noise) n = (double)noise[los * N + m];
-            else {
-                const unsigned long long idx = (unsigned long long)los * N + m;
-                double g0, g1, g2, g3;
-                mode_noise_pair<double>(idx, 1u, rkey, g0, g1, g2, g3);
-                n = g0;
-            }
-            vel = vel + sigma_nl * n;
-        }
+        if (sigma_nl > 0.0) vel = vel + sigma_nl * (double)nz[e];
         const double s = zg[m] - vel / Hz;
         double r = fmod_pos(s - zmin, len);           // numpy % : result takes the divisor's sign
         if (r != 0.0) { if (r < 0.0) r += len; } else r = 0.0;

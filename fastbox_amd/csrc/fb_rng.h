@@ -113,4 +113,14 @@ __device__ __forceinline__ void mode_noise_pair(unsigned long long idx, uint32_t
     box_muller(o[2], o[3], b0, b1);
 }
 
+// Small-scale velocity noise of the redshift-space remap (stream 1): element idx of the (N,N,N)
+// grid takes output idx & 3 of call idx >> 2, so four consecutive line-of-sight cells share one call.
+template <typename T>
+__device__ __forceinline__ T los_noise_at(unsigned long long idx, const RngKey& key) {
+    T g0, g1, g2, g3;
+    mode_noise_pair<T>(idx >> 2, 1u, key, g0, g1, g2, g3);
+    const int r = (int)(idx & 3ull);
+    return r == 0 ? g0 : (r == 1 ? g1 : (r == 2 ? g2 : g3));
+}
+
 }  // namespace fb

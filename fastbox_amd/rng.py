@@ -70,9 +70,11 @@ def half_spectrum_noise(N, seed, realisation, dtype=np.float64):
 
 
 def los_noise(N, seed, dtype=np.float64):
-    """Standard normals n(i,j,m) of the redshift-space small-scale velocities (stream 1)."""
-    idx = np.arange(N ** 3, dtype=np.uint64)
+    """Standard normals n(i,j,m) of the redshift-space small-scale velocities (stream 1): element
+    idx of the (N,N,N) grid is output idx & 3 of call idx >> 2 (fb_rng.h los_noise_at)."""
+    q = np.arange(N ** 3 // 4, dtype=np.uint64)
     key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, 0, 0)
-    o = threefry4x32_20((idx & _M32, idx >> np.uint64(32), np.uint64(1), np.uint64(0)), key)
-    g0, _ = box_muller(o[0], o[1], np.float64)
-    return g0.reshape(N, N, N)
+    o = threefry4x32_20((q & _M32, q >> np.uint64(32), np.uint64(1), np.uint64(0)), key)
+    g0, g1 = box_muller(o[0], o[1], dtype)
+    g2, g3 = box_muller(o[2], o[3], dtype)
+    return np.stack([g0, g1, g2, g3], axis=-1).reshape(N, N, N)
