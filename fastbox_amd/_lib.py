@@ -50,6 +50,7 @@ SIGNATURES = {
     "fb_expand_half": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_crop_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_realise_density_device": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p, c_void_p]),
+    "fb_realise_velocity_device": (c_int, [c_void_p, c_u64, c_u64, c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "fb_realise_density_begin": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p]),
     "fb_realise_density_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_power_spectrum_pending": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

@@ -101,9 +101,14 @@ class LazySpectrum(DeviceArray):
     """A k-space field computed by `make()` on first use (e.g. one velocity component: callers of the
     reference usually transform only v_z, box.py:285 returns all three)."""
 
-    def __init__(self, engine, kind, make):
+    def __init__(self, engine, kind, make, recipe=None):
         DeviceArray.__init__(self, engine, kind, None)
         self._make = make
+        self.recipe = recipe      # (amp_key, seed, realisation, comp, fac) of a device-RNG velocity component
+
+    @property
+    def materialised(self):
+        return self._buf is not None
 
     @property
     def ptr(self):
@@ -118,9 +123,10 @@ class PendingDensity(DeviceArray):
     runs that pass; ``binned_power_spectrum(delta_x=...)`` of it (or of its log-normal) instead
     fuses the pass with the power spectrum's first one, and fills in delta_x on the way."""
 
-    def __init__(self, engine, pending_half):
+    def __init__(self, engine, pending_half, generator=None):
         DeviceArray.__init__(self, engine, REAL, None)
         self._pending = pending_half
+        self.generator = generator      # (amp_key, seed, realisation): enough to regenerate delta_k
 
     @property
     def materialised(self):
@@ -246,6 +252,11 @@ class CosmoBox(object):
     def to_real(self, field_k):
         """Real part of ifftn(field_k) as a device field (what callers of the reference
         write as ``np.fft.ifftn(box.velocity_k[2]).real``)."""
+        if isinstance(field_k, LazySpectrum) and field_k.recipe is not None and not field_k.materialised:
+            # velocity of a device-RNG realisation: regenerate delta_k inside the first inverse pass
+            amp_key, seed, realisation, comp, fac = field_k.recipe
+            self._set_amplitude(*amp_key)
+            return self.engine.realise_velocity_fused(seed, realisation, comp, fac)
         f = self._as_spectrum(field_k)
         if f.kind == HALF:
             return self.engine.fft_c2r(f)
@@ -302,7 +313,8 @@ class CosmoBox(object):
         else:
             # generator fused into the first inverse FFT pass (no coloured spectrum round trip); the
             # last pass is deferred so that a following P(k) can fuse it with its own first pass
-            delta_x = PendingDensity(eng, eng.realise_begin(self.seed, self._realisation))
+            delta_x = PendingDensity(eng, eng.realise_begin(self.seed, self._realisation),
+                                     generator=(self._amp_key, self.seed, self._realisation))
             self.last_realisation = self._realisation
             self._realisation += 1
         if inplace:
@@ -328,13 +340,30 @@ class CosmoBox(object):
         if redshift is None:
             redshift = self.redshift
         scale_factor = 1. / (1. + redshift)
-        dk = self._field_k(delta_x, delta_k)
+        if delta_x is not None and delta_k is not None:
+            raise ValueError("delta_x and delta_k specified; can only specify one")
         if self.N % 2 != 0:
             raise UnboundLocalError("local variable 'mx' referenced before assignment")
         fac = 100. * self.cosmo['h'] * _ccl.h_over_h0(self.cosmo, a=scale_factor) \
             * _ccl.growth_rate(self.cosmo, a=scale_factor) * scale_factor
-        velocity_k = tuple(LazySpectrum(self.engine, dk.kind, lambda c=c: self.engine.velocity_k(dk, c, fac))
-                           for c in range(3))        # each component is computed when first used
+        src = getattr(self, "delta_x", None)
+        if delta_x is None and delta_k is None and self._delta_k is None \
+                and isinstance(src, PendingDensity) and src.generator is not None:
+            # the stored realisation came from the counter-based generator: delta_k = fftn(delta_x) is only
+            # formed if a component is read in k space; to_real() regenerates it inside its first FFT pass
+            box, cache = self, {}
+
+            def dk_of():
+                if "dk" not in cache:
+                    cache["dk"] = box._delta_k if box.delta_x is src and box._delta_k is not None \
+                        else box.engine.fft_r2c(src)
+                return cache["dk"]
+            velocity_k = tuple(LazySpectrum(self.engine, HALF, lambda c=c: self.engine.velocity_k(dk_of(), c, fac),
+                                            recipe=src.generator + (c, fac)) for c in range(3))
+        else:
+            dk = self._field_k(delta_x, delta_k)
+            velocity_k = tuple(LazySpectrum(self.engine, dk.kind, lambda c=c: self.engine.velocity_k(dk, c, fac))
+                               for c in range(3))    # each component is computed when first used
         if inplace:
             self.velocity_k = velocity_k
         return velocity_k

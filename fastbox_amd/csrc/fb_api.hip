@@ -245,6 +245,16 @@ int fb_realise_density_device(fb_plan* p, uint64_t seed, uint64_t realisation, v
     return FB_DISPATCH(p, fbi_realise_fused_f32(p, seed, realisation, work_half, real_out, scale, s),
                        fbi_realise_fused_f64(p, seed, realisation, work_half, real_out, scale, s));
 }
+int fb_realise_velocity_device(fb_plan* p, uint64_t seed, uint64_t realisation, int comp, double fac,
+                               void* work_half, void* real_out, void* stream) {
+    FB_REQUIRE(p && work_half && real_out, "null pointer");
+    FB_REQUIRE(comp >= 0 && comp <= 2, "component must be 0, 1 or 2");
+    FB_REQUIRE(p->N % 2 == 0, "velocity needs an even grid size");
+    hipStream_t s = (hipStream_t)stream;
+    const double scale = 1.0 / ((double)p->N * p->N * p->N);
+    return FB_DISPATCH(p, fbi_realise_velocity_fused_f32(p, seed, realisation, comp, fac, work_half, real_out, scale, s),
+                       fbi_realise_velocity_fused_f64(p, seed, realisation, comp, fac, work_half, real_out, scale, s));
+}
 int fb_realise_density_begin(fb_plan* p, uint64_t seed, uint64_t realisation, void* pending_half, void* stream) {
     FB_REQUIRE(p && pending_half, "null pointer");
     hipStream_t s = (hipStream_t)stream;

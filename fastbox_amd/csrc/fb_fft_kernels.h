@@ -62,6 +62,8 @@ template <typename T> struct StridedOp {
     double* partial;     // BIN: [2 * nbins][gridDim.x]
     int nbins, namb, store;
     int outer0;          // global index of this launch's first outer (k_y) row
+    int vel_on, vel_comp;   // GEN: emit i fac delta_k k_c / k^2 (velocity component) instead of delta_k
+    double vel_fac;
     int amb[8];
 };
 
@@ -183,6 +185,28 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             const int amy = my < 0 ? -my : my;
             const T* sym0 = op.amp.sym + ((long long)t * ((N >> 1) + 1) + amy) * op.g.NZP + col;
             const T* sym1 = op.amp.sym + ((long long)((N >> 1) - t) * ((N >> 1) + 1) + amy) * op.g.NZP + col;
+            // velocity mode (single precision): fetch the per-row terms of k^2 and k_c now, so that the
+            // loads are in flight while the random numbers are computed
+            [[maybe_unused]] float vs0[E / 2], vs1[E / 2], vk0[E / 2], vk1[E / 2];
+            if constexpr (sizeof(T) == 4) {
+                if (op.vel_on) {
+                    const int cmp = op.vel_comp;
+                    const int kzc = col < op.g.NZV ? col : 0;                      // padding columns: any valid entry
+                    const float syz = (float)(op.g.axis2[N + ky] + op.g.axis2[2 * N + kzc]);
+                    const int icf = cmp == 1 ? ky : kzc;
+                    const float kcf = (float)(op.g.ksc[cmp * N + icf] * op.vel_fac);
+#pragma unroll
+                    for (int j = 0; j < E / 2; ++j) {
+                        const int kx = t + j * TPL, kh = kx + (N >> 1);
+                        vs0[j] = (float)op.g.axis2[kx] + syz;
+                        vs1[j] = (float)op.g.axis2[kh] + syz;
+                        vk0[j] = cmp == 0 ? (float)(op.g.ksc[kx] * op.vel_fac) : kcf;
+                        vk1[j] = cmp == 0 ? (float)(op.g.ksc[kh] * op.vel_fac) : kcf;
+                        if ((cmp == 0 ? kx : icf) == (N >> 1)) vk0[j] = 0.f;       // Nyquist plane of the component
+                        if ((cmp == 0 ? kh : icf) == (N >> 1)) vk1[j] = 0.f;
+                    }
+                }
+            }
             uint32_t ctr[E / 2][4], rnd[E / 2][4];
 #pragma unroll
             for (int j = 0; j < E / 2; ++j) {
@@ -215,6 +239,22 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     }
                     v[j] = cx<T>{A0 * a0, A0 * a1};
                     v[j + E / 2] = cx<T>{A1 * b0, A1 * b1};
+                    if (op.vel_on) {      // wave-uniform: the velocity field of the same realisation
+                        const int kh = kx + (N >> 1), cmp = op.vel_comp;
+                        if constexpr (sizeof(T) == 4) {
+                            // single precision: k_c fac / k^2, k^2 = 4 pi^2 (s_x + (s_y + s_z)), hardware reciprocal
+                            const float m0 = vs0[j] > 0.f ? vk0[j] * __builtin_amdgcn_rcpf(39.47841760435743f * vs0[j]) : 0.f;
+                            const float m1 = vs1[j] > 0.f ? vk1[j] * __builtin_amdgcn_rcpf(39.47841760435743f * vs1[j]) : 0.f;
+                            v[j] = cx<T>{-v[j].y * m0, v[j].x * m0};
+                            v[j + E / 2] = cx<T>{-v[j + E / 2].y * m1, v[j + E / 2].x * m1};
+                        } else {
+                            const double ay = op.g.axis2[N + ky], az = op.g.axis2[2 * N + col];   // kmag_exact's order
+                            v[j] = velocity_of<T>(op.g, cmp, op.vel_fac, cmp == 0 ? kx : (cmp == 1 ? ky : col),
+                                                  (op.g.axis2[kx] + ay) + az, v[j]);
+                            v[j + E / 2] = velocity_of<T>(op.g, cmp, op.vel_fac, cmp == 0 ? kh : (cmp == 1 ? ky : col),
+                                                          (op.g.axis2[kh] + ay) + az, v[j + E / 2]);
+                        }
+                    }
                 } else {
                     v[j] = cx<T>{0, 0};
                     v[j + E / 2] = cx<T>{0, 0};

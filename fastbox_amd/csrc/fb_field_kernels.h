@@ -346,6 +346,27 @@ void k_apply_filter(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, Filte
 // box.py:251-284: A_c = i delta_k k_c / k^2, NaN -> 0, plane m_c = -N/2 zeroed, times fac.
 // fp64 plans follow the reference's operation order (k = 2 pi sqrt(.), k^2 = k k, two divisions);
 // fp32 plans form k_c fac / k^2 once per mode with a single-precision division (3e-7 relative).
+// s2 = (m_x/L_x)^2 + (m_y/L_y)^2 + (m_z/L_z)^2 summed in kmag_exact's order; ic = index along comp.
+template <typename T>
+__device__ __forceinline__ cx<T> velocity_of(const KGeom& g, int comp, double fac, int ic, double s2, cx<T> d) {
+#pragma clang fp contract(off)
+    cx<T> v{0, 0};
+    if (s2 > 0.0 && ic != (g.N >> 1)) {
+        const double kc = g.ksc[comp * g.N + ic];
+        if constexpr (sizeof(T) == 4) {
+            const float m = (float)(kc * fac) / (float)((FB_TWO_PI * FB_TWO_PI) * s2);
+            v.x = -d.y * m;
+            v.y = d.x * m;
+        } else {
+            const double k = FB_TWO_PI * sqrt(s2);
+            const double k2 = k * k;
+            // (i d) * kc / k2  with i d = (-d.y, d.x)
+            v.x = (T)(((double)(-d.y) * kc) / k2 * fac);
+            v.y = (T)(((double)d.x * kc) / k2 * fac);
+        }
+    }
+    return v;
+}
 template <typename T>
 __global__ __launch_bounds__(64 * FB_ROW_GROUPS)
 void k_velocity(const cx<T>* __restrict__ dk, cx<T>* __restrict__ out, KGeom g, int comp, double fac, int pitch, int nz) {
@@ -358,22 +379,7 @@ void k_velocity(const cx<T>* __restrict__ dk, cx<T>* __restrict__ out, KGeom g, 
 #pragma clang fp contract(off)
         const int ic = comp == 0 ? i : (comp == 1 ? j : l);
         const double s2 = rowsum + g.axis2[2 * g.N + l];
-        const cx<T> d = dk[base + l];
-        cx<T> v{0, 0};
-        if (s2 > 0.0 && ic != (g.N >> 1)) {
-            const double kc = g.ksc[comp * g.N + ic];
-            if constexpr (sizeof(T) == 4) {
-                const float m = (float)(kc * fac) / (float)((FB_TWO_PI * FB_TWO_PI) * s2);
-                v.x = -d.y * m;
-                v.y = d.x * m;
-            } else {
-                const double k = FB_TWO_PI * sqrt(s2);
-                const double k2 = k * k;
-                // (i d) * kc / k2  with i d = (-d.y, d.x)
-                v.x = (T)(((double)(-d.y) * kc) / k2 * fac);
-                v.y = (T)(((double)d.x * kc) / k2 * fac);
-            }
-        }
+        const cx<T> v = velocity_of<T>(g, comp, fac, ic, s2, dk[base + l]);
         out[base + l] = v;
     }
 }

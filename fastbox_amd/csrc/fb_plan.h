@@ -113,6 +113,8 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_sumsq_half_##sfx(fb_plan* p, const void* h, double* out, hipStream_t s); \
     int fbi_expand_half_##sfx(fb_plan* p, const void* h, void* f, hipStream_t s); \
     int fbi_crop_full_##sfx(fb_plan* p, const void* f, void* h, hipStream_t s); \
+    int fbi_realise_velocity_fused_##sfx(fb_plan* p, uint64_t seed, uint64_t real, int comp, double fac, \
+                                         void* work_half, void* real_out, double scale, hipStream_t s); \
     int fbi_realise_fused_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* work_half, void* real_out, \
                                 double scale, hipStream_t s); \
     int fbi_power_fused_##sfx(fb_plan* p, const void* real_in, void* work_half, int pre_exp, int store, \

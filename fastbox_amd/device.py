@@ -345,6 +345,15 @@ class Engine(object):
                   int(realisation) & (2 ** 64 - 1), self._scratch_half().ptr, out.ptr, self.stream)
         return out
 
+    def realise_velocity_fused(self, seed, realisation, comp, fac):
+        """Re ifftn(v_comp(k)) of the device-RNG realisation (seed, realisation), regenerated inside the
+        first inverse FFT pass: no delta_k, no v(k) in memory."""
+        out = self.empty(REAL)
+        _lib.call("fb_realise_velocity_device", self._plan, int(seed) & (2 ** 64 - 1),
+                  int(realisation) & (2 ** 64 - 1), int(comp), float(fac), self._scratch_half().ptr, out.ptr,
+                  self.stream)
+        return out
+
     def realise_begin(self, seed, realisation):
         """Generator + x and y passes; returns the pending half spectrum (z pass still to do)."""
         pend = self.empty(HALF)

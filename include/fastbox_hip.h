@@ -81,6 +81,13 @@ int fb_colour_device(fb_plan* plan, uint64_t seed, uint64_t realisation, void* h
 int fb_realise_density_device(fb_plan* plan, uint64_t seed, uint64_t realisation, void* work_half,
                               void* real_out, void* stream);
 
+/* velocity component `comp` (0 x, 1 y, 2 z) of the SAME realisation in real space:
+ * real_out = Re ifftn(i fac delta_k k_c / k^2) (realise_velocity, box.py:251-284, then the caller's
+ * np.fft.ifftn(velocity_k[c]).real, e.g. examples/example_redshift_space.py:17).  The counter-based
+ * generator reproduces delta_k inside the first pass; no spectrum is stored.  work_half is scratch. */
+int fb_realise_velocity_device(fb_plan* plan, uint64_t seed, uint64_t realisation, int comp, double fac,
+                               void* work_half, void* real_out, void* stream);
+
 /* deferred form of the above: _begin runs the generator + x and y passes into `pending_half`
  * (half-spectrum sized); the z pass is done later by _finish (real_out = delta_x), or by
  * fb_power_spectrum_pending, which fuses it with the first pass of the power spectrum: real_out is

@@ -153,6 +153,29 @@ def test_redshift_space_cells_per_lane(N, vscale):
     assert np.max(np.abs(got - want)) < 1e-12 * np.max(np.abs(want))
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("f64", 1e-10)])
+@pytest.mark.parametrize("scale", [3e2, (1e2, 2e2, 4e2)])
+def test_velocity_in_real_space_regenerated_by_the_generator(prec, tol, scale):
+    """to_real(velocity_k[c]) of a device-RNG realisation regenerates delta_k inside its first FFT pass
+    (fb_realise_velocity_device); it must equal the stored-spectrum route fftn(delta_x) -> v(k) -> ifftn."""
+    from fastbox_amd import CosmoBox, default_cosmo
+    box = CosmoBox(cosmo=default_cosmo, box_scale=scale, nsamp=64, realise_now=False, precision=prec,
+                   rng="device", seed=4)
+    dx = box.realise_density()
+    vel = box.realise_velocity()
+    assert vel is box.velocity_k and len(vel) == 3
+    for c in range(3):
+        assert not vel[c].materialised
+        fast = np.asarray(box.to_real(vel[c]))
+        assert not vel[c].materialised                              # nothing was stored in k space
+        slow = np.asarray(box.to_real(box.realise_velocity(delta_x=dx, inplace=False)[c]))
+        assert np.max(np.abs(fast - slow)) < tol * np.sqrt(np.mean(slow ** 2)), c
+    # a component read in k space still materialises through delta_k = fftn(delta_x)
+    vk = np.asarray(vel[2])
+    ref = np.asarray(box.realise_velocity(delta_x=dx, inplace=False)[2])
+    assert np.max(np.abs(vk - ref)) <= tol * np.max(np.abs(ref))
+
+
 class _ReplayNormals(object):
     """Stands in for np.random in the oracle: hands out a prepared (N,N,N) noise cube line by line."""
 

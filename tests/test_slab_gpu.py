@@ -49,15 +49,25 @@ def test_virtual_ranks_match_single_gpu(P, precision, tol):
 
 def _gloo_worker(rank, world, port, out_dir, N, L, seed):
     import os
+    import sys
+    import time
+    t0 = time.time()
+    def mark(what):
+        sys.stderr.write("[slabworker %d] %6.1f s %s\n" % (rank, time.time() - t0, what)); sys.stderr.flush()
     import torch.distributed as dist
+    mark("torch.distributed imported")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    mark("process group up")
     try:
         from fastbox_amd import default_cosmo
         from fastbox_amd.distributed import SlabBox
         box = SlabBox(default_cosmo, box_scale=L, nsamp=N, precision="f32", seed=seed, device=0)
+        mark("SlabBox built")
         dx = box.realise_density().double().cpu().numpy()
+        mark("density realised")
         pk = box.binned_power_spectrum(nbins=20, lognormal=True)
+        mark("power spectrum done")
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), dx=dx, pk=np.array(pk))
     finally:
         dist.destroy_process_group()
