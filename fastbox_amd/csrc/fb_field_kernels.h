@@ -566,6 +566,7 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
     const double zmin = zg[0], zmax = zg[N - 1];
     const double len = zmax - zmin;
     const double inv_dz = (double)(N - 1) / len;
+    [[maybe_unused]] const double inv_Hz = 1.0 / Hz, inv_len = 1.0 / len;
     u64 kb[E];
     int cell[E];
     T val[E];
@@ -590,9 +591,19 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         const int m = lane * E + e;
         double vel = (double)v[m];
         if (sigma_nl > 0.0) vel = vel + sigma_nl * (double)nz[e];
-        const double s = zg[m] - vel / Hz;
-        double r = fmod_pos(s - zmin, len);           // numpy % : result takes the divisor's sign
-        if (r != 0.0) { if (r < 0.0) r += len; } else r = 0.0;
+        double r;
+        if constexpr (sizeof(T) == 4) {
+            // single-precision plans: the inputs carry 1e-7 relative error, so reciprocals replace the two
+            // fp64 divisions (displacement, wrap); the wrap still lands in [0, len)
+            const double a = (zg[m] - vel * inv_Hz) - zmin;
+            r = fma(-floor(a * inv_len), len, a);
+            if (r < 0.0) r += len;
+            if (r >= len) r -= len;
+        } else {
+            const double s = zg[m] - vel / Hz;
+            r = fmod_pos(s - zmin, len);              // numpy % : result takes the divisor's sign
+            if (r != 0.0) { if (r < 0.0) r += len; } else r = 0.0;
+        }
         const double key = r + zmin;
         int c = (int)((key - zmin) * inv_dz);
         c = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
@@ -651,11 +662,18 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         else {
             const double kj = order_value(kmx[run_below]), vj = (double)vmx[run_below];
             const double kn = order_value(kmn[ab[e]]), vn = (double)vmn[ab[e]];
-            const double slope = (vn - vj) / (kn - kj);
-            y = slope * (x - kj) + vj;
-            if (y != y) {
-                y = slope * (x - kn) + vn;
-                if (y != y && vj == vn) y = vj;
+            if constexpr (sizeof(T) == 4) {
+                // differences in fp64 (close keys cancel), the quotient in fp32
+                const float w = (float)(x - kj) / (float)(kn - kj);
+                y = (double)(vmx[run_below] + (vmn[ab[e]] - vmx[run_below]) * w);
+                if (y != y) y = vj == vn ? vj : y;
+            } else {
+                const double slope = (vn - vj) / (kn - kj);
+                y = slope * (x - kj) + vj;
+                if (y != y) {
+                    y = slope * (x - kn) + vn;
+                    if (y != y && vj == vn) y = vj;
+                }
             }
         }
         y_out[e] = (T)y;

@@ -176,6 +176,24 @@ def test_velocity_in_real_space_regenerated_by_the_generator(prec, tol, scale):
     assert np.max(np.abs(vk - ref)) <= tol * np.max(np.abs(ref))
 
 
+@pytest.mark.parametrize("N,vscale", [(64, 900.), (256, 60.)])
+def test_redshift_space_single_precision_plan(N, vscale):
+    """fp32 plans take arithmetic shortcuts in the remap (reciprocals, fp32 interpolation weight): on
+    fp32-representable inputs the result must still be the oracle's to fp32 rounding (a bracket may
+    flip on a cell or two where a shifted key lands within 1e-16 of a grid point)."""
+    from fastbox_amd import CosmoBox, default_cosmo
+    rng = np.random.RandomState(21)
+    box = CosmoBox(cosmo=default_cosmo, box_scale=2e2, nsamp=N, realise_now=False, precision="f32")
+    geo = bo.box_geometry(2e2, N)
+    d = rng.normal(size=(N, N, N)).astype(np.float32).astype(np.float64)
+    v = (vscale * rng.normal(size=(N, N, N))).astype(np.float32).astype(np.float64)
+    Hz = standin.hubble(standin.cosmology(), 1.0)
+    want = bo.redshift_space_density(geo, d, v, Hz, 0.)
+    got = np.asarray(box.redshift_space_density(delta_x=d, velocity_z=v, sigma_nl=0.))
+    bad = np.abs(got - want) > 2e-6 * np.max(np.abs(want))
+    assert bad.sum() <= 3
+
+
 class _ReplayNormals(object):
     """Stands in for np.random in the oracle: hands out a prepared (N,N,N) noise cube line by line."""
 
