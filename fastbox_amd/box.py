@@ -179,6 +179,7 @@ class CosmoBox(object):
         self._cubic = (self.Lx == self.Ly == self.Lz)
         self._grids = None
         self._amp_key = None
+        self._bin_cache = {}
         self._delta_k = None
         self.set_fft_sample_spacing()
         self.engine = Engine(self.N, (self.Lx, self.Ly, self.Lz), self._axis2, self._ksc, self._kpar, self.z,
@@ -473,6 +474,29 @@ class CosmoBox(object):
         thr = np.searchsorted(hi, np.arange(1, bins.size + 1), side="left")
         return thr.astype(np.int32), tuple(int(a) for a in amb)
 
+    def _bin_setup(self, nbins, kbins):
+        """Edges, centres of bins 1..nbins-1 (box.py:745-751) and the shell thresholds, remembered per
+        bin set: a Monte-Carlo loop asks for the same bins every realisation."""
+        key = ("n", int(nbins)) if kbins is None else ("k", np.asarray(kbins, dtype=np.float64).tobytes())
+        hit = self._bin_cache.get(key)
+        if hit is not None:
+            return hit
+        if kbins is not None:
+            bins = np.array(kbins, dtype=np.float64)
+        else:
+            bins = np.logspace(np.log10(self.kmin), np.log10(self.kmax), nbins)   # box.py:749
+        _bins = [0.0] + list(bins)
+        cent = [0.5 * (_bins[j + 1] + _bins[j]) for j in range(bins.size)]
+        kc = np.array(cent[1:])
+        thr, amb = (None, ())
+        if self._cubic and np.all(np.diff(bins) >= 0):
+            thr, amb = self._shell_thresholds(bins)
+        bins.setflags(write=False)
+        if len(self._bin_cache) > 16:
+            self._bin_cache.clear()
+        self._bin_cache[key] = (bins, kc, thr, amb)
+        return self._bin_cache[key]
+
     def binned_power_spectrum(self, delta_x=None, delta_k=None, nbins=20, kbins=None, wait=True):
         """Shell-averaged power spectrum of the realisation (box.py:696-768): bin centres,
         mean of |delta_k|^2/boxfactor and std/sqrt(n) per bin; bin 0 is dropped and empty
@@ -481,17 +505,8 @@ class CosmoBox(object):
         many realisations can be queued without a host round trip each."""
         if delta_x is not None and delta_k is not None:
             raise ValueError("delta_x and delta_k specified; can only specify one")
-        if kbins is not None:
-            bins = np.asarray(kbins, dtype=np.float64)
-        else:
-            bins = np.logspace(np.log10(self.kmin), np.log10(self.kmax), nbins)   # box.py:749
-        _bins = [0.0] + list(bins)
-        cent = [0.5 * (_bins[j + 1] + _bins[j]) for j in range(bins.size)]
-        kc = np.array(cent[1:])
-
-        thr, amb = (None, ())
-        if self._cubic and np.all(np.diff(bins) >= 0):
-            thr, amb = self._shell_thresholds(bins)
+        bins, kc, thr, amb = self._bin_setup(nbins, kbins)
+        kc = kc.copy()                    # callers own what they get back
         eng = self.engine
         eng.set_bins(bins, thr, amb)
 
