@@ -39,6 +39,8 @@ SIGNATURES = {
     "fb_colour_device": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p]),
     "fb_set_bins": (c_int, [c_void_p, P_double, c_int, P_i32, P_i32, c_int]),
     "fb_bin_power": (c_int, [c_void_p, c_void_p, c_int, P_double, P_double, P_double, c_void_p]),
+    "fb_bin_power_filtered": (c_int, [c_void_p, c_void_p, c_int, c_int, P_double, c_void_p, P_double, P_double,
+                                      P_double, c_void_p]),
     "fb_apply_filter": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, P_double, c_void_p, c_void_p]),
     "fb_velocity_k": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p]),
     "fb_potential_k": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

@@ -118,6 +118,36 @@ class LazySpectrum(DeviceArray):
         return self._buf.ptr
 
 
+class FilteredField(DeviceArray):
+    """ifftn(field_k * T(k_perp, k_par)) for a Hermitian device spectrum and a k_par-even ``DeviceFilter``
+    (apply_transfer_fn, box.py:356-381), formed when it is first read.  ``binned_power_spectrum`` of it
+    (or of its ``.real``) bins |field_k T|^2 straight from ``field_k``: no filtered spectrum is stored and no
+    transform runs for the power spectrum."""
+
+    def __init__(self, engine, spectrum, filt, as_complex=True, parent=None):
+        DeviceArray.__init__(self, engine, REAL, None, as_complex)
+        self.spectrum, self.filter, self._parent = spectrum, filt, parent
+
+    @property
+    def materialised(self):
+        return self._buf is not None
+
+    @property
+    def ptr(self):
+        if self._buf is None:
+            if self._parent is not None:
+                self._parent.ptr
+                self._buf = self._parent._buf
+            else:
+                dk = self.engine.apply_filter(self.spectrum, self.filter.kind, self.filter.params)
+                self._buf = self.engine.fft_c2r(dk, destroy=True)._buf
+        return self._buf.ptr
+
+    @property
+    def real(self):
+        return FilteredField(self.engine, self.spectrum, self.filter, as_complex=False, parent=self)
+
+
 class PendingDensity(DeviceArray):
     """delta_x of a device-RNG realisation whose last (z) FFT pass has not run yet.  Reading it
     runs that pass; ``binned_power_spectrum(delta_x=...)`` of it (or of its log-normal) instead
@@ -404,7 +434,9 @@ class CosmoBox(object):
         eng = self.engine
         f = self._as_spectrum(field_k)
         if isinstance(transfer_fn, DeviceFilter):
-            if f.kind == HALF and not transfer_fn.even_in_kpar:
+            if f.kind == HALF and transfer_fn.even_in_kpar:
+                return FilteredField(eng, f, transfer_fn)      # lazy: see the class
+            if f.kind == HALF:
                 f = eng.expand_half(f)
             dk = eng.apply_filter(f, transfer_fn.kind, transfer_fn.params)
         else:
@@ -509,6 +541,13 @@ class CosmoBox(object):
         kc = kc.copy()                    # callers own what they get back
         eng = self.engine
         eng.set_bins(bins, thr, amb)
+
+        if isinstance(delta_x, FilteredField):
+            # P(k) of apply_transfer_fn's result = shell sums of |field_k T|^2 (Hermitian field, even filter)
+            eng.set_bins(bins, thr, amb)
+            cnt, s1, s2 = eng.bin_power(delta_x.spectrum, filt=(delta_x.filter.kind, delta_x.filter.params))
+            out = (kc,) + _finish_bins(cnt, s1, s2, self.boxfactor)
+            return out if wait else _Ready(out)
 
         if delta_x is not None and thr is not None:
             # fused path (cubic boxes): r2c with the binning inside the last pass

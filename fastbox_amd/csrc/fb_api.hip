@@ -76,7 +76,7 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
     if (!r) r = upload(&p->ksc, ksc, (size_t)3 * N);
     if (!r) r = upload(&p->kpar, kpar, (size_t)N);
     if (!r) r = upload(&p->zgrid, zgrid, (size_t)N);
-    p->prow = 1024;
+    p->prow = 2048;      // 8 four-wave workgroups per CU
     if (!r) r = fb_hip_check(hipMalloc((void**)&p->partials, (size_t)p->prow * 2 * FB_MAX_BINS * sizeof(double)), "hipMalloc");
     if (!r) r = fb_hip_check(hipMalloc((void**)&p->scratch, FB_SCRATCH * sizeof(double)), "hipMalloc");
     if (!r) r = fb_hip_check(hipMalloc((void**)&p->counts, FB_MAX_BINS * sizeof(unsigned long long)), "hipMalloc");
@@ -164,11 +164,14 @@ int fb_set_bins(fb_plan* p, const double* edges, int nbins, const int32_t* thr, 
     return fbi_bin_count(p, 0);
 }
 
-int fb_bin_power(fb_plan* p, const void* spec, int layout, double* count, double* sum, double* sumsq, void* stream) {
+namespace {
+int bin_power_common(fb_plan* p, const void* spec, int layout, int kind, const double* params, const void* table_dev,
+                     double* count, double* sum, double* sumsq, void* stream) {
     FB_REQUIRE(p && spec && count && sum && sumsq, "null pointer");
     FB_REQUIRE(layout == 0 || layout == 1, "layout must be 0 (full) or 1 (half)");
     hipStream_t s = (hipStream_t)stream;
-    int r = FB_DISPATCH(p, fbi_bin_power_f32(p, spec, layout, p->scratch, s), fbi_bin_power_f64(p, spec, layout, p->scratch, s));
+    int r = FB_DISPATCH(p, fbi_bin_power_f32(p, spec, layout, kind, params, table_dev, p->scratch, s),
+                        fbi_bin_power_f64(p, spec, layout, kind, params, table_dev, p->scratch, s));
     if (r) return r;
     std::vector<double> h((size_t)2 * p->nbins);
     FB_HIP(hipMemcpyAsync(h.data(), p->scratch, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -179,6 +182,16 @@ int fb_bin_power(fb_plan* p, const void* spec, int layout, double* count, double
         sumsq[q] = h[(size_t)2 * q + 1];
     }
     return FB_OK;
+}
+}  // namespace
+
+int fb_bin_power(fb_plan* p, const void* spec, int layout, double* count, double* sum, double* sumsq, void* stream) {
+    return bin_power_common(p, spec, layout, -1, nullptr, nullptr, count, sum, sumsq, stream);
+}
+int fb_bin_power_filtered(fb_plan* p, const void* spec, int layout, int kind, const double* params,
+                          const void* table_dev, double* count, double* sum, double* sumsq, void* stream) {
+    FB_REQUIRE(kind >= 0, "unknown filter kind");
+    return bin_power_common(p, spec, layout, kind, params, table_dev, count, sum, sumsq, stream);
 }
 
 int fb_apply_filter(fb_plan* p, const void* in, void* out, int layout, int kind, const double* params,

@@ -67,26 +67,6 @@ template <typename T> struct StridedOp {
     int amb[8];
 };
 
-__device__ __forceinline__ int shell_bin(const int* lthr, int nbins, int n2) {
-    int lo = 0, hi = nbins;                       // number of thr[] <= n2
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (lthr[mid] <= n2) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-
-// every lane of the wave calls this; lanes with `have` add (s1, s2) to bin b of the wave's row
-__device__ __forceinline__ void wave_flush(int b, double s1, double s2, bool have, double* row) {
-    unsigned long long rem = __ballot(have);
-    const int lane = threadIdx.x & 63;
-    while (rem) {
-        const int lead = __ffsll((long long)rem) - 1;
-        const int bl = __shfl(b, lead, 64);
-        const bool mine = have && b == bl;
-        const double r1 = wave_sum(mine ? s1 : 0.0), r2 = wave_sum(mine ? s2 : 0.0);
-        if (lane == 0) { row[2 * bl] += r1; row[2 * bl + 1] += r2; }
-        rem &= ~__ballot(mine);
-    }
-}
-
 // Persistent workgroups: each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and issues
 // the global loads of its next tile before transforming the current one, so that HBM requests
 // stay in flight through the LDS exchanges and the fused epilogue.
@@ -151,7 +131,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     cx<T> v[E];
     [[maybe_unused]] cx<T> vn[E];
     [[maybe_unused]] int wb_lo = 0, wb_hi = 0, wb_edge = 0x7fffffff;   // BIN: this wave's bins (see epilogue)
-    [[maybe_unused]] bool wb_ok = false;
+    [[maybe_unused]] bool wb_ok = false, wb_rng = false;
     int tile_id = blockIdx.x;
     if constexpr (MODE != SMODE_GEN && PERSIST == 1) {          // the launcher guarantees gridDim.x <= ntiles
         const int bx0 = tile_id % a.ntx;
@@ -302,7 +282,8 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             wb_hi = __builtin_amdgcn_readfirstlane(shell_bin(op.thr, op.nbins, whi));
             bool hit = false;
             for (int z = 0; z < op.namb; ++z) hit |= (op.amb[z] >= wlo && op.amb[z] <= whi);
-            wb_ok = !hit && wb_hi - wb_lo <= 1;
+            wb_rng = hit;                          // an edge-shell lies in the wave's n^2 RANGE: look closer below
+            wb_ok = wb_hi - wb_lo <= 1;
             wb_edge = (wb_ok && wb_hi > wb_lo) ? op.thr[wb_lo] : 0x7fffffff;       // first n^2 of bin wb_hi
         }
         FB_STAMP(3);
@@ -344,10 +325,20 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             bool done = false;
             if constexpr ((64 * E) % TZ == 0 && (N / 2) % ((64 * E) / TZ) == 0 && TZ % E == 0) {
                 const int blo = wb_lo, bhi = wb_hi, edge = wb_edge;
-                if (wb_ok) {
-                    const int mx = mode_of(off0 / TZ, N);
-                    const int n2row = mx * mx + my2;
-                    const int kz0 = col0 + off0 % TZ;
+                const int mx = mode_of(off0 / TZ, N);
+                const int n2row = mx * mx + my2;
+                const int kz0 = col0 + off0 % TZ;
+                bool exact = false;                // does a mode of this wave sit ON one of the edge-shells?
+                if (wb_ok && wb_rng) {
+                    bool mine = false;
+#pragma unroll
+                    for (int q = 0; q < E; ++q) {
+                        const int n2 = n2row + (kz0 + q) * (kz0 + q);
+                        for (int z = 0; z < op.namb; ++z) mine |= (op.amb[z] == n2) && (kz0 + q < a.ncols);
+                    }
+                    exact = __any(mine);
+                }
+                if (wb_ok && !exact) {
                     // tiles away from the k_z = 0 and k_z >= N/2 columns: every mode is stored once
                     // for itself and once for its mirror image (weight 2, applied after the sums)
                     const bool inner = col0 > 0 && col0 + TZ <= (N >> 1);

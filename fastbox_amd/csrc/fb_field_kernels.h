@@ -155,55 +155,26 @@ __device__ __forceinline__ int bin_of_mode(const BinGeom& bg, const KGeom& g, co
     return bin_exact(lbins, bg.nbins, kmag_exact(g, i, j, l));
 }
 
-// partial[block][2*nbins] = (sum w p, sum w p^2), p = |delta_k|^2, w = multiplicity of the
-// stored mode in the full grid (2 for 0 < k_z < N/2).  Deterministic: lane-group private
-// LDS slots, fixed-order reduction.
-template <typename T>
-__global__ __launch_bounds__(64 * FB_BIN_WAVES)
-void k_bin_half(const cx<T>* __restrict__ half, double* __restrict__ partial, KGeom g, BinGeom bg, int rep,
-                int full_layout) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* lbins = reinterpret_cast<double*>(smem);
-    double* acc = lbins + bg.nbins;                                   // [waves][nbins][rep][2]
-    int* lthr = reinterpret_cast<int*>(acc + FB_BIN_WAVES * bg.nbins * rep * 2);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int q = tid; q < bg.nbins; q += blockDim.x) { lbins[q] = bg.bins[q]; lthr[q] = bg.thr ? bg.thr[q] : 0; }
-    for (int q = tid; q < FB_BIN_WAVES * bg.nbins * rep * 2; q += blockDim.x) acc[q] = 0.0;
-    __syncthreads();
-    double* my = acc + (size_t)wave * bg.nbins * rep * 2;
-    const int slot = lane & (rep - 1);
-    const long long nrows = (long long)g.N * g.N;
-    for (long long row = (long long)blockIdx.x * FB_BIN_WAVES + wave; row < nrows;
-         row += (long long)gridDim.x * FB_BIN_WAVES) {
-        const int i = (int)(row / g.N), j = (int)(row % g.N);
-        const int nz = full_layout ? g.N : g.NZV, pitch = full_layout ? g.N : g.NZP;
-        for (int l = lane; l < nz; l += 64) {
-            const int b = bin_of_mode(bg, g, lbins, lthr, i, j, l);
-            if (b < bg.nbins) {
-                const cx<T> d = half[(full_layout ? row : (long long)i * g.NR + j) * pitch + l];
-                const double p = (double)(d.x * d.x + d.y * d.y);
-                const double w = (full_layout || l == 0 || l == (g.N >> 1)) ? 1.0 : 2.0;
-                atomicAdd(&my[(b * rep + slot) * 2 + 0], w * p);
-                atomicAdd(&my[(b * rep + slot) * 2 + 1], w * p * p);
-            }
-        }
+// out[q] = sum over workgroups of partial[q][workgroup]; fixed order (thread-strided chains, LDS tree)
+static __global__ __launch_bounds__(256) void k_bin_finish(const double* __restrict__ partial, int nblocks, int nvals,
+                                                           double* __restrict__ out) {
+    __shared__ double sh[256];
+    const int q = blockIdx.x;
+    const double* src = partial + (size_t)q * nblocks;
+    double c[4] = {0, 0, 0, 0};
+    int r = threadIdx.x;
+    for (; r + 3 * 256 < nblocks; r += 4 * 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] += src[r + u * 256];
     }
+    for (int u = 0; r < nblocks; r += 256, ++u) c[u & 3] += src[r];
+    sh[threadIdx.x] = (c[0] + c[1]) + (c[2] + c[3]);
     __syncthreads();
-    for (int q = tid; q < 2 * bg.nbins; q += blockDim.x) {
-        const int b = q >> 1, c = q & 1;
-        double s = 0.0;
-        for (int w = 0; w < FB_BIN_WAVES; ++w)
-            for (int r = 0; r < rep; ++r) s += acc[(((size_t)w * bg.nbins + b) * rep + r) * 2 + c];
-        partial[(size_t)blockIdx.x * 2 * bg.nbins + q] = s;
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
     }
-}
-
-static __global__ void k_bin_finish(const double* __restrict__ partial, int nblocks, int nvals, double* __restrict__ out) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nvals) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * nvals + q];
-    out[q] = s;
+    if (threadIdx.x == 0) out[q] = sh[0];
 }
 
 // number of full-grid modes per bin (data independent; done once per bin set)
@@ -248,6 +219,43 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// min / max of an int over the wave (same DPP ladder as wave_sum; `old` = the identity element)
+template <bool MAX>
+__device__ __forceinline__ int wave_minmax(int v) {
+    constexpr int ident = MAX ? (int)0x80000000 : 0x7fffffff;
+#define FB_DPP_MM(ctrl, rmask, bmask) do { \
+        const int o = __builtin_amdgcn_update_dpp(ident, v, ctrl, rmask, bmask, false); \
+        v = MAX ? (o > v ? o : v) : (o < v ? o : v); } while (0)
+    FB_DPP_MM(0x111, 0xf, 0xf);
+    FB_DPP_MM(0x112, 0xf, 0xf);
+    FB_DPP_MM(0x114, 0xf, 0xe);
+    FB_DPP_MM(0x118, 0xf, 0xc);
+    FB_DPP_MM(0x142, 0xa, 0xf);
+    FB_DPP_MM(0x143, 0xc, 0xf);
+#undef FB_DPP_MM
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ int shell_bin(const int* lthr, int nbins, int n2) {
+    int lo = 0, hi = nbins;                       // number of thr[] <= n2
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (lthr[mid] <= n2) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// every lane of the wave calls this; lanes with `have` add (s1, s2) to bin b of the wave's row
+__device__ __forceinline__ void wave_flush(int b, double s1, double s2, bool have, double* row) {
+    unsigned long long rem = __ballot(have);
+    const int lane = threadIdx.x & 63;
+    while (rem) {
+        const int lead = __ffsll((long long)rem) - 1;
+        const int bl = __shfl(b, lead, 64);
+        const bool mine = have && b == bl;
+        const double r1 = wave_sum(mine ? s1 : 0.0), r2 = wave_sum(mine ? s2 : 0.0);
+        if (lane == 0) { row[2 * bl] += r1; row[2 * bl + 1] += r2; }
+        rem &= ~__ballot(mine);
+    }
+}
+
 // block partial sums of f(x); OP 0: x, 1: x^2, 2: exp(x) (also written to out)
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void k_reduce_real(const T* __restrict__ in, T* __restrict__ out, long long n,
@@ -339,6 +347,113 @@ void k_apply_filter(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, Filte
         const T m = filter_value<T>(f, g, i, j, l, base + l, kperp);
         const cx<T> d = in[base + l];
         out[base + l] = cx<T>{nan_to_num(d.x * m), nan_to_num(d.y * m)};
+    }
+}
+
+// ---- stand-alone shell binning of a stored spectrum (box.py:741-764) ----------------------------------
+// partial[2*nbins][block] = (sum w p, sum w p^2), p = |delta_k|^2 (times T(k)^2 when a filter is given:
+// the power spectrum of apply_transfer_fn's result without storing the filtered spectrum), w = multiplicity
+// of the stored mode in the full grid (2 for 0 < k_z < N/2 of a half spectrum).
+// One (k_x, k_y) row per wave, 64 consecutive k_z per step.  Cubic boxes: the n^2 range of the step is
+// wave-uniform, so the step lies in one bin or straddles one edge almost always -- each lane splits at that
+// edge, four DPP wave sums, one lane adds into the wave's fp64 row.  Otherwise (several edges, a shell
+// within rounding of an edge, non-cubic box): bin per lane, one reduction per distinct bin (wave_flush).
+// Deterministic: fixed row -> wave assignment, fixed-order reductions.
+#define FB_BIN_GROUP 5
+template <typename T>
+__global__ __launch_bounds__(64 * FB_BIN_WAVES)
+void k_bin_rows(const cx<T>* __restrict__ spec, double* __restrict__ partial, KGeom g, BinGeom bg, FilterSpec f,
+                int full_layout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lbins = reinterpret_cast<double*>(smem);
+    double* acc = lbins + bg.nbins;                                   // [waves][2 nbins]
+    int* lthr = reinterpret_cast<int*>(acc + FB_BIN_WAVES * bg.nbins * 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = bg.nbins, N = g.N;
+    for (int q = tid; q < nb; q += blockDim.x) { lbins[q] = bg.bins[q]; lthr[q] = bg.thr ? bg.thr[q] : 0; }
+    for (int q = tid; q < FB_BIN_WAVES * nb * 2; q += blockDim.x) acc[q] = 0.0;
+    __syncthreads();
+    double* row_acc = acc + (size_t)wave * nb * 2;
+    const int nz = full_layout ? N : g.NZV, pitch = full_layout ? N : g.NZP;
+    const long long nrows = (long long)N * N;
+    for (long long row = (long long)blockIdx.x * FB_BIN_WAVES + wave; row < nrows;
+         row += (long long)gridDim.x * FB_BIN_WAVES) {
+        const int i = (int)(row / N), j = (int)(row % N);
+        const long long base = (full_layout ? row : (long long)i * g.NR + j) * pitch;
+        const int mx = mode_of(i, N), my = mode_of(j, N);
+        const int n2row = mx * mx + my * my;
+        const double kperp = f.kind >= 0 ? kperp_exact(g, i, j) : 0.0;
+        const bool mono = !full_layout && N >= 128;
+        int bprev = 0;                                                 // bins below the row's first mode: found by the first step
+        for (int g0 = 0; g0 < nz; g0 += 64 * FB_BIN_GROUP) {
+            // all loads of the group first (a half-spectrum row of N <= 512 is one group): one request in
+            // flight per wave would leave the kernel latency-bound
+            cx<T> dv[FB_BIN_GROUP];
+#pragma unroll
+            for (int c = 0; c < FB_BIN_GROUP; ++c) {
+                const int l = g0 + 64 * c + lane;
+                dv[c] = l < nz ? spec[base + l] : cx<T>{0, 0};
+            }
+#pragma unroll
+            for (int c = 0; c < FB_BIN_GROUP; ++c) {
+                const int l0 = g0 + 64 * c;
+                if (l0 >= nz) break;                                   // wave-uniform
+                const int l = l0 + lane;
+                const bool ok = l < nz;
+                cx<T> d = dv[c];
+                if (ok && f.kind >= 0) {
+                    const T m = filter_value<T>(f, g, i, j, l, base + l, kperp);
+                    d = cx<T>{nan_to_num(d.x * m), nan_to_num(d.y * m)};
+                }
+                const T p = d.x * d.x + d.y * d.y;
+                const T w = (full_layout || l == 0 || l == (N >> 1)) ? (T)1 : (T)2;
+                const int ml = mode_of(l, N);
+                const int n2 = n2row + ml * ml;
+                bool done = false;
+                if (bg.thr) {
+                    int blo, bhi;
+                    if (mono) {
+                        // half-spectrum row, 64-aligned steps: n^2 grows with k_z, so the step's bounds are
+                        // its end points and the bins only move forward from the previous step's
+                        const int lend = l0 + 63 < nz ? l0 + 63 : nz - 1;
+                        const int wlo = n2row + l0 * l0, whi = n2row + lend * lend;
+                        blo = bprev;
+                        while (blo < nb && lthr[blo] <= wlo) ++blo;
+                        bhi = blo;
+                        while (bhi < nb && lthr[bhi] <= whi) ++bhi;
+                        bprev = blo;
+                    } else {
+                        const int wlo = wave_minmax<false>(ok ? n2 : 0x7fffffff), whi = wave_minmax<true>(ok ? n2 : -1);
+                        blo = shell_bin(lthr, nb, wlo); bhi = shell_bin(lthr, nb, whi);
+                    }
+                    bool mine = false;                 // a mode sitting ON a shell that needs the exact |k|
+                    for (int z = 0; z < bg.namb; ++z) mine |= ok && (bg.amb[z] == n2);
+                    if (bhi - blo <= 1 && !__any(mine)) {
+                        const int edge = (bhi > blo) ? lthr[blo] : 0x7fffffff;   // first n^2 of bin bhi
+                        const bool up = n2 >= edge;
+                        const T wp = ok ? w * p : (T)0, wp2 = wp * p;
+                        const T s1 = wave_sum(up ? (T)0 : wp), s2 = wave_sum(up ? (T)0 : wp2);
+                        if (bhi > blo) {
+                            const T u1 = wave_sum(up ? wp : (T)0), u2 = wave_sum(up ? wp2 : (T)0);
+                            if (lane == 0 && bhi < nb) { row_acc[2 * bhi] += (double)u1; row_acc[2 * bhi + 1] += (double)u2; }
+                        }
+                        if (lane == 0 && blo < nb) { row_acc[2 * blo] += (double)s1; row_acc[2 * blo + 1] += (double)s2; }
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    const int b = ok ? bin_of_mode(bg, g, lbins, lthr, i, j, l) : nb;
+                    const double pd = (double)p, wd = (double)w;
+                    wave_flush(b, wd * pd, wd * pd * pd, ok && b < nb, row_acc);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < 2 * nb; q += blockDim.x) {
+        double s = 0.0;
+        for (int w = 0; w < FB_BIN_WAVES; ++w) s += acc[(size_t)w * nb * 2 + q];
+        partial[(size_t)q * gridDim.x + blockIdx.x] = s;          // [value][workgroup]: see k_sum_columns
     }
 }
 

@@ -101,7 +101,8 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_set_amp_shells_##sfx(fb_plan* p, const double* amp, int64_t n); \
     int fbi_colour_noise_##sfx(fb_plan* p, const void* re, const void* im, void* out, hipStream_t s); \
     int fbi_colour_device_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* out, hipStream_t s); \
-    int fbi_bin_power_##sfx(fb_plan* p, const void* spec, int layout, double* sums_dev, hipStream_t s); \
+    int fbi_bin_power_##sfx(fb_plan* p, const void* spec, int layout, int filter_kind, const double* prm, \
+                            const void* table, double* sums_dev, hipStream_t s); \
     int fbi_apply_filter_##sfx(fb_plan* p, const void* in, void* out, int layout, int kind, const double* prm, \
                                const void* table, hipStream_t s); \
     int fbi_velocity_##sfx(fb_plan* p, const void* dk, void* out, int layout, int comp, double fac, hipStream_t s); \

@@ -290,13 +290,18 @@ class Engine(object):
         self._bins_key = key
         self._nbins = edges.size
 
-    def bin_power(self, spec):
-        """(count, sum |dk|^2, sum |dk|^4) per bin over the full grid."""
+    def bin_power(self, spec, filt=None):
+        """(count, sum |dk|^2, sum |dk|^4) per bin over the full grid; with ``filt`` = (kind, params) the
+        sums are those of spec * T(k_perp, k_par), the filtered spectrum itself is never stored."""
         nb = self._nbins
         cnt, s1, s2 = (np.zeros(nb) for _ in range(3))
-        _lib.call("fb_bin_power", self._plan, spec.ptr, 1 if spec.kind == HALF else 0,
-                  cnt.ctypes.data_as(_lib.P_double),
-                  s1.ctypes.data_as(_lib.P_double), s2.ctypes.data_as(_lib.P_double), self.stream)
+        outs = (cnt.ctypes.data_as(_lib.P_double), s1.ctypes.data_as(_lib.P_double), s2.ctypes.data_as(_lib.P_double))
+        if filt is None:
+            _lib.call("fb_bin_power", self._plan, spec.ptr, 1 if spec.kind == HALF else 0, *outs, self.stream)
+        else:
+            prm = (ctypes.c_double * 4)(*[float(x) for x in filt[1]])
+            _lib.call("fb_bin_power_filtered", self._plan, spec.ptr, 1 if spec.kind == HALF else 0, int(filt[0]), prm,
+                      None, *outs, self.stream)
         return cnt, s1, s2
 
     # -- k-space operators -----------------------------------------------------------

@@ -105,6 +105,11 @@ int fb_set_bins(fb_plan* plan, const double* edges, int nbins, const int32_t* th
  * sumsq[nbins] = sum |dk|^4.  Synchronises the stream.                                       */
 int fb_bin_power(fb_plan* plan, const void* spec, int layout, double* count, double* sum, double* sumsq,
                  void* stream);
+/* the same sums of spec * T(k_perp, k_par) (filter kinds and params as fb_apply_filter): the power
+ * spectrum of apply_transfer_fn's result (box.py:356-381 then :741-764) for a real, k_par-even filter,
+ * without storing the filtered spectrum or transforming back and forth.                      */
+int fb_bin_power_filtered(fb_plan* plan, const void* spec, int layout, int kind, const double* params,
+                          const void* table_dev, double* count, double* sum, double* sumsq, void* stream);
 
 /* fused path for cubic boxes (needs fb_set_bins with thr): r2c of real_in (of exp(real_in) when
  * pre_exp) with the binning inside the last pass.  Asynchronous: results_dev[2*nbins+1] (DEVICE)

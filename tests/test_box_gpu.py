@@ -153,6 +153,36 @@ def test_redshift_space_cells_per_lane(N, vscale):
     assert np.max(np.abs(got - want)) < 1e-12 * np.max(np.abs(want))
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("f64", 1e-10)])
+@pytest.mark.parametrize("scale", [1e3, (1e2, 2e2, 4e2)])
+def test_power_spectrum_of_filtered_field_without_transforms(prec, tol, scale):
+    """apply_transfer_fn with a k_par-even device filter is lazy; its P(k) is binned from field_k * T directly
+    (fb_bin_power_filtered) and must equal the reference's route: ifftn, then fftn inside
+    binned_power_spectrum (box.py:379 then :741)."""
+    from fastbox_amd import CosmoBox, default_cosmo, Wedge, BeamHighpass
+    from fastbox_amd.box import FilteredField
+    np.random.seed(12)
+    box = CosmoBox(cosmo=default_cosmo, box_scale=scale, nsamp=64, realise_now=False, precision=prec)
+    box.realise_density()
+    dk = box.delta_k
+    for filt in (Wedge(slope=0.4, kpar_min=0.01), BeamHighpass(kpar0=0.02, kperp0=0.3, power=2.)):
+        lazy = box.apply_transfer_fn(dk, filt)
+        assert isinstance(lazy, FilteredField) and not lazy.materialised
+        kc, pk, err = box.binned_power_spectrum(delta_x=lazy.real, nbins=16)
+        assert not lazy.materialised                                   # no transform ran
+        field = np.asarray(lazy)                                       # now it does: ifftn(dk T)
+        assert field.dtype == np.complex128 and np.max(np.abs(field.imag)) == 0.
+        k_perp = 2. * np.pi * np.sqrt((box.Kx / box.Lx) ** 2. + (box.Ky / box.Ly) ** 2.)      # box.py:374-375
+        k_par = 2. * np.pi * box.Kz / box.Lz
+        want_field = np.fft.ifftn(np.nan_to_num(np.asarray(dk) * filt(k_perp, k_par)))
+        assert np.max(np.abs(field.real - want_field.real)) < 20 * tol * np.std(want_field.real)
+        kc2, pk2, err2 = box.binned_power_spectrum(delta_x=box.engine.upload(field.real, "real"), nbins=16)
+        assert np.array_equal(kc, kc2) and np.array_equal(np.isnan(pk), np.isnan(pk2))
+        m = ~np.isnan(pk2)
+        assert np.allclose(pk[m], pk2[m], rtol=tol, atol=tol * np.max(pk2[m]) * 1e-6)
+        assert np.allclose(err[m], err2[m], rtol=100 * tol, atol=tol * np.max(pk2[m]))
+
+
 @pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("f64", 1e-10)])
 @pytest.mark.parametrize("scale", [3e2, (1e2, 2e2, 4e2)])
 def test_velocity_in_real_space_regenerated_by_the_generator(prec, tol, scale):
