@@ -55,6 +55,7 @@ SIGNATURES = {
     "fb_realise_velocity_device": (c_int, [c_void_p, c_u64, c_u64, c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "fb_realise_density_begin": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p]),
     "fb_realise_density_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fb_power_spectrum_filtered": (c_int, [c_void_p, c_void_p, c_void_p, c_int, P_double, c_void_p, c_void_p, c_void_p]),
     "fb_power_spectrum_pending": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "fb_power_spectrum_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fb_bin_counts": (c_int, [c_void_p, P_double]),

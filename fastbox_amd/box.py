@@ -101,10 +101,11 @@ class LazySpectrum(DeviceArray):
     """A k-space field computed by `make()` on first use (e.g. one velocity component: callers of the
     reference usually transform only v_z, box.py:285 returns all three)."""
 
-    def __init__(self, engine, kind, make, recipe=None):
+    def __init__(self, engine, kind, make, recipe=None, source_real=None):
         DeviceArray.__init__(self, engine, kind, None)
         self._make = make
         self.recipe = recipe      # (amp_key, seed, realisation, comp, fac) of a device-RNG velocity component
+        self.source_real = source_real    # to_k(field): the real field this is the (pending) transform of
 
     @property
     def materialised(self):
@@ -121,12 +122,17 @@ class LazySpectrum(DeviceArray):
 class FilteredField(DeviceArray):
     """ifftn(field_k * T(k_perp, k_par)) for a Hermitian device spectrum and a k_par-even ``DeviceFilter``
     (apply_transfer_fn, box.py:356-381), formed when it is first read.  ``binned_power_spectrum`` of it
-    (or of its ``.real``) bins |field_k T|^2 straight from ``field_k``: no filtered spectrum is stored and no
-    transform runs for the power spectrum."""
+    (or of its ``.real``) needs no transform of its own: it bins |field_k T|^2 from ``field_k``; when
+    ``field_k`` is itself a pending ``CosmoBox.to_k(field)``, the multiply, the binning and the store of the
+    filtered spectrum all happen inside the last pass of that forward transform."""
 
     def __init__(self, engine, spectrum, filt, as_complex=True, parent=None):
         DeviceArray.__init__(self, engine, REAL, None, as_complex)
         self.spectrum, self.filter, self._parent = spectrum, filt, parent
+        self._filtered = None            # field_k * T once a fused P(k) has produced it
+
+    def _root(self):
+        return self if self._parent is None else self._parent._root()
 
     @property
     def materialised(self):
@@ -135,11 +141,14 @@ class FilteredField(DeviceArray):
     @property
     def ptr(self):
         if self._buf is None:
-            if self._parent is not None:
-                self._parent.ptr
-                self._buf = self._parent._buf
+            root = self._root()
+            if root is not self:
+                root.ptr
+                self._buf = root._buf
             else:
-                dk = self.engine.apply_filter(self.spectrum, self.filter.kind, self.filter.params)
+                dk = self._filtered if self._filtered is not None else \
+                    self.engine.apply_filter(self.spectrum, self.filter.kind, self.filter.params)
+                self._filtered = None
                 self._buf = self.engine.fft_c2r(dk, destroy=True)._buf
         return self._buf.ptr
 
@@ -279,6 +288,13 @@ class CosmoBox(object):
     @delta_k.setter
     def delta_k(self, value):
         self._delta_k = None if value is None else self._as_spectrum(value)
+
+    def to_k(self, field):
+        """fftn(field) of a real field as a device half spectrum (what callers of the reference write as
+        ``np.fft.fftn(field)``), formed on first use: ``apply_transfer_fn`` + ``binned_power_spectrum`` of
+        it run as one forward transform with the filter and the binning inside its last pass."""
+        real = self._as_real(field)
+        return LazySpectrum(self.engine, HALF, lambda: self.engine.fft_r2c(real), source_real=real)
 
     def to_real(self, field_k):
         """Real part of ifftn(field_k) as a device field (what callers of the reference
@@ -544,8 +560,17 @@ class CosmoBox(object):
 
         if isinstance(delta_x, FilteredField):
             # P(k) of apply_transfer_fn's result = shell sums of |field_k T|^2 (Hermitian field, even filter)
-            eng.set_bins(bins, thr, amb)
-            cnt, s1, s2 = eng.bin_power(delta_x.spectrum, filt=(delta_x.filter.kind, delta_x.filter.params))
+            root, src = delta_x._root(), delta_x.spectrum
+            filt = (delta_x.filter.kind, delta_x.filter.params)
+            if root._filtered is None and not root.materialised and thr is not None \
+                    and isinstance(src, LazySpectrum) and src.source_real is not None and not src.materialised:
+                res, root._filtered = eng.power_filtered(src.source_real, filt)
+                pending = PendingSpectrum(eng, res, bins.size, kc, self.boxfactor, None, None)
+                return pending if not wait else pending.result()
+            if root._filtered is not None:
+                cnt, s1, s2 = eng.bin_power(root._filtered)
+            else:
+                cnt, s1, s2 = eng.bin_power(src, filt=filt)
             out = (kc,) + _finish_bins(cnt, s1, s2, self.boxfactor)
             return out if wait else _Ready(out)
 

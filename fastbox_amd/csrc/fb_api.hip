@@ -76,6 +76,12 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
     if (!r) r = upload(&p->ksc, ksc, (size_t)3 * N);
     if (!r) r = upload(&p->kpar, kpar, (size_t)N);
     if (!r) r = upload(&p->zgrid, zgrid, (size_t)N);
+    if (!r) {          // k_perp per (k_x, k_y), the value kperp_exact() forms on the device (IEEE sqrt, same order)
+        std::vector<double> kp((size_t)N * N);
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) kp[(size_t)i * N + j] = 6.283185307179586476925286766559 * std::sqrt(axis2[i] + axis2[N + j]);
+        r = upload(&p->kperp_tab, kp.data(), kp.size());
+    }
     p->prow = 2048;      // 8 four-wave workgroups per CU
     if (!r) r = fb_hip_check(hipMalloc((void**)&p->partials, (size_t)p->prow * 2 * FB_MAX_BINS * sizeof(double)), "hipMalloc");
     if (!r) r = fb_hip_check(hipMalloc((void**)&p->scratch, FB_SCRATCH * sizeof(double)), "hipMalloc");
@@ -90,7 +96,7 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
 
 int fb_plan_destroy(fb_plan* p) {
     if (!p) return FB_OK;
-    void* ptrs[] = {p->tw, p->axis2, p->ksc, p->kpar, p->zgrid, p->amp_shell, p->amp_sym, p->bins, p->thr, p->counts,
+    void* ptrs[] = {p->tw, p->axis2, p->ksc, p->kpar, p->zgrid, p->amp_shell, p->amp_sym, p->kperp_tab, p->bins, p->thr, p->counts,
                     p->partials, p->scratch, p->bin_partials, p->exp_partials};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     delete p;
@@ -280,6 +286,13 @@ int fb_realise_density_finish(fb_plan* p, void* pending_half, void* real_out, vo
     const double scale = 1.0 / ((double)p->N * p->N * p->N);
     return FB_DISPATCH(p, fbi_realise_finish_f32(p, pending_half, real_out, scale, s),
                        fbi_realise_finish_f64(p, pending_half, real_out, scale, s));
+}
+int fb_power_spectrum_filtered(fb_plan* p, const void* real_in, void* filtered_half, int kind, const double* params,
+                               const void* table_dev, void* results_dev, void* stream) {
+    FB_REQUIRE(p && real_in && filtered_half && results_dev, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_power_filtered_f32(p, real_in, filtered_half, kind, params, table_dev, (double*)results_dev, s),
+                       fbi_power_filtered_f64(p, real_in, filtered_half, kind, params, table_dev, (double*)results_dev, s));
 }
 int fb_power_spectrum_pending(fb_plan* p, void* pending_half, void* real_out, int pre_exp, double* results_dev,
                               void* stream) {

@@ -34,7 +34,10 @@ template <typename T> constexpr int tile_cols(int n) {
 #ifndef FB_OCC
 #define FB_OCC(x) 1      // let the allocator use what the prefetching loop needs (no spills)
 #endif
-enum { SMODE_PLAIN = 0, SMODE_GEN = 1, SMODE_BIN = 2 };
+enum { SMODE_PLAIN = 0, SMODE_GEN = 1, SMODE_BIN = 2, SMODE_BINF = 3 };
+// BINF: as BIN, but the spectrum is multiplied by a k_perp/k_par filter first and written out: the last
+// forward pass of "P(k) of apply_transfer_fn's result", leaving the filtered spectrum for the inverse.
+constexpr bool smode_bins(int mode) { return mode == SMODE_BIN || mode == SMODE_BINF; }
 
 template <typename T> struct StridedArgs {
     const cx<T>* in;
@@ -64,6 +67,8 @@ template <typename T> struct StridedOp {
     int outer0;          // global index of this launch's first outer (k_y) row
     int vel_on, vel_comp;   // GEN: emit i fac delta_k k_c / k^2 (velocity component) instead of delta_k
     double vel_fac;
+    FilterSpec filt;        // BINF
+    const double* kperp_tab;   // BINF: 2 pi sqrt((m_x/L_x)^2 + (m_y/L_y)^2) per (k_x, k_y)
     int amb[8];
 };
 
@@ -85,7 +90,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     cx<T>* tile = reinterpret_cast<cx<T>*>(smem);
     cx<T>* twl = tile + N * TZ;
     double* acc = reinterpret_cast<double*>(twl + N);          // BIN: [NW][2 nbins], whole launch
-    int* lthr = reinterpret_cast<int*>(acc + (size_t)NW * 2 * (MODE == SMODE_BIN ? op.nbins : 0));
+    int* lthr = reinterpret_cast<int*>(acc + (size_t)NW * 2 * (smode_bins(MODE) ? op.nbins : 0));
 
     const int tid = threadIdx.x;
     const int c = tid % TZ;
@@ -101,7 +106,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     // first butterflies.
     auto load_tables = [&]() {
         for (int i = tid; i < N; i += NT) twl[i] = a.tw[i];
-        if constexpr (MODE == SMODE_BIN) {
+        if constexpr (smode_bins(MODE)) {
             for (int i = tid; i < NW * 2 * op.nbins; i += NT) acc[i] = 0.0;
             for (int i = tid; i < op.nbins; i += NT) lthr[i] = op.thr[i];
         }
@@ -109,10 +114,10 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     if constexpr (PERSIST) load_tables();
     TileLayout<T, TZ> lay{tile, c};
 #ifdef FB_STAMPS      // diagnostic build only: phase time stamps of every workgroup (tools/stamps.py)
-    long long* stamp = (MODE == SMODE_BIN)
+    long long* stamp = (smode_bins(MODE))
         ? reinterpret_cast<long long*>(op.partial + (size_t)2 * op.nbins * gridDim.x) + (size_t)blockIdx.x * 8
         : reinterpret_cast<long long*>(const_cast<double*>(op.bins)) + (size_t)blockIdx.x * 8;
-    const bool stamp_ok = (MODE == SMODE_BIN) ? (op.partial != nullptr) : (op.bins != nullptr);
+    const bool stamp_ok = (smode_bins(MODE)) ? (op.partial != nullptr) : (op.bins != nullptr);
 #define FB_STAMP(k) do { if (tid == 0 && stamp_ok) stamp[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     FB_STAMP(0);
 #else
@@ -139,7 +144,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         const unsigned voff = bx0 * TZ + c < a.ncols ? loff : FB_BUF_OOB;
 #pragma unroll
         for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + e * estep), voff, src);
-        if constexpr (MODE != SMODE_BIN) {
+        if constexpr (!smode_bins(MODE)) {
             // E stores that the range check discards: they make the memory-op queue at loop entry
             // look like the queue at the back edge (E loads, then E stores), so that the compiler's
             // merged s_waitcnt for "previous prefetch has landed" is vmcnt(E) on both paths instead
@@ -266,7 +271,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 #endif
         if constexpr (PERSIST) __syncthreads();   // LDS of the previous tile's epilogue is free again
         else load_tables();
-        if constexpr (MODE == SMODE_BIN && (64 * E) % TZ == 0 && (N / 2) % ((64 * E) / TZ) == 0 && TZ % E == 0) {
+        if constexpr (smode_bins(MODE) && (64 * E) % TZ == 0 && (N / 2) % ((64 * E) / TZ) == 0 && TZ % E == 0) {
             // The bins of this wave's block of the tile depend on the tile's coordinates only: look
             // them up now, with scalar loads from the global threshold table, while the tile's data
             // is still on its way from HBM.
@@ -288,19 +293,33 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         }
         FB_STAMP(3);
         if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
-        else if constexpr (MODE == SMODE_BIN) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);
+        else if constexpr (smode_bins(MODE)) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);
         else {
             if (sign < 0) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);
             else          fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
         }
         FB_STAMP(4);
-        if constexpr (MODE != SMODE_BIN) {
+        if constexpr (MODE == SMODE_BINF) {
+            // multiply by T(k_perp, k_par) (box.py:374-379; k_perp from the plan's [k_x][k_y] table, the
+            // same fp64 value k_apply_filter computes), nan_to_num, keep the filtered spectrum
+            const int kyf = by + op.outer0;
+            if (valid) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int kx = t + e * TPL;
+                    const long long idx = ((long long)kx * op.g.NR + kyf) * op.g.NZP + col;
+                    const T m = filter_value<T>(op.filt, op.g, kx, kyf, col, idx, op.kperp_tab[(long long)kx * N + kyf]);
+                    v[e] = cx<T>{nan_to_num(v[e].x * m), nan_to_num(v[e].y * m)};
+                }
+            }
+        }
+        if constexpr (!smode_bins(MODE) || MODE == SMODE_BINF) {
             cx<T>* dst = a.out + ubase + tbase;
             const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
 #pragma unroll
             for (int e = 0; e < E; ++e) buf_store(make_rsrc(dst + e * estep), voff, cscale(v[e], a.scale));
         }
-        if constexpr (MODE == SMODE_BIN) {
+        if constexpr (smode_bins(MODE)) {
             // Re-stage p = |X|^2 through LDS so that each lane bins E consecutive elements of
             // one k_x row neighbourhood and each wave 64*E/TZ consecutive rows: a lane's modes
             // then span a narrow range of |k| (almost always one bin) and a wave needs one
@@ -429,14 +448,14 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             }   // !done
         }
 #ifdef FB_STAMPS
-        if constexpr (MODE != SMODE_BIN) FB_STAMP(5);
+        if constexpr (!smode_bins(MODE)) FB_STAMP(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FB_STAMP(6);
 #endif
         if constexpr (!PERSIST) break;
         tile_id += gridDim.x;
     } while (tile_id < a.ntiles);
-    if constexpr (MODE == SMODE_BIN) {
+    if constexpr (smode_bins(MODE)) {
         __syncthreads();
         const int nb = op.nbins;
         for (int i = tid; i < 2 * nb; i += NT) {          // partial[value][workgroup]

@@ -35,6 +35,7 @@ struct fb_plan {
     void* amp_shell = nullptr;   // [nshell] plan precision, index n^2 = i^2+j^2+l^2 (cubic only)
     int64_t nshell = 0;
     const void* amp_dense = nullptr;  // caller-owned [N][N][NZP]
+    double* kperp_tab = nullptr; // [N][N] 2 pi sqrt((m_x/L_x)^2 + (m_y/L_y)^2), box.py:374
     void* amp_sym = nullptr;     // [N/2+1][N/2+1][NZP] plan precision: amp_shell spread over (|m_x|, |m_y|, k_z)
 
     // P(k) binning (box.py:745-764)
@@ -101,6 +102,8 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_set_amp_shells_##sfx(fb_plan* p, const double* amp, int64_t n); \
     int fbi_colour_noise_##sfx(fb_plan* p, const void* re, const void* im, void* out, hipStream_t s); \
     int fbi_colour_device_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* out, hipStream_t s); \
+    int fbi_power_filtered_##sfx(fb_plan* p, const void* real_in, void* filtered_half, int kind, const double* prm, \
+                                 const void* table, double* results, hipStream_t s); \
     int fbi_bin_power_##sfx(fb_plan* p, const void* spec, int layout, int filter_kind, const double* prm, \
                             const void* table, double* sums_dev, hipStream_t s); \
     int fbi_apply_filter_##sfx(fb_plan* p, const void* in, void* out, int layout, int kind, const double* prm, \

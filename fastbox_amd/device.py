@@ -388,6 +388,16 @@ class Engine(object):
                   1 if keep_spectrum else 0, res.ptr, self.stream)
         return res, (work if keep_spectrum else None)
 
+    def power_filtered(self, real, filt):
+        """Asynchronous r2c of `real` whose last pass multiplies by the filter (kind, params), keeps the
+        filtered spectrum and bins it.  Returns (results buffer, filtered half spectrum)."""
+        res = self._alloc_bytes((2 * self._nbins + 1) * 8)
+        out = self.empty(HALF)
+        prm = (ctypes.c_double * 4)(*[float(x) for x in filt[1]])
+        _lib.call("fb_power_spectrum_filtered", self._plan, real.ptr, out.ptr, int(filt[0]), prm, None, res.ptr,
+                  self.stream)
+        return res, out
+
     def fetch_results(self, res, nbins):
         h = np.empty(2 * nbins + 1)
         _lib.call("fb_memcpy_d2h", _ptr(h), res.ptr, h.nbytes, self.stream)

@@ -111,6 +111,14 @@ int fb_bin_power(fb_plan* plan, const void* spec, int layout, double* count, dou
 int fb_bin_power_filtered(fb_plan* plan, const void* spec, int layout, int kind, const double* params,
                           const void* table_dev, double* count, double* sum, double* sumsq, void* stream);
 
+/* fused "filter + estimate" for cubic boxes (needs fb_set_bins with thr): the power spectrum of
+ * ifftn(fftn(real_in) * T(k_perp, k_par)) for a real, k_par-even filter -- apply_transfer_fn followed by
+ * binned_power_spectrum (box.py:356-381, :696-768).  r2c and y pass, then the x pass multiplies by T,
+ * writes the FILTERED spectrum to filtered_half (fb_fft_c2r of it delivers the filtered field) and bins
+ * it.  Asynchronous; results_dev as for fb_power_spectrum_device.                              */
+int fb_power_spectrum_filtered(fb_plan* plan, const void* real_in, void* filtered_half, int kind,
+                               const double* params, const void* table_dev, void* results_dev, void* stream);
+
 /* fused path for cubic boxes (needs fb_set_bins with thr): r2c of real_in (of exp(real_in) when
  * pre_exp) with the binning inside the last pass.  Asynchronous: results_dev[2*nbins+1] (DEVICE)
  * receives (sum |dk|^2, sum |dk|^4) per bin, then sum(exp(real_in)) (0 unless pre_exp).

@@ -183,6 +183,33 @@ def test_power_spectrum_of_filtered_field_without_transforms(prec, tol, scale):
         assert np.allclose(err[m], err2[m], rtol=100 * tol, atol=tol * np.max(pk2[m]))
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("f64", 1e-10)])
+@pytest.mark.parametrize("N", [64, 256])
+def test_filter_and_power_spectrum_inside_the_forward_transform(prec, tol, N):
+    """to_k(field) -> apply_transfer_fn -> binned_power_spectrum as ONE forward transform whose last pass
+    multiplies by T, stores the filtered spectrum and bins it (fb_power_spectrum_filtered); the filtered
+    field then comes from that stored spectrum.  Against the step-by-step route."""
+    from fastbox_amd import CosmoBox, default_cosmo, Wedge, BeamHighpass
+    box = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False, precision=prec, rng="device", seed=6)
+    dx = box.realise_density()
+    np.asarray(dx)
+    for filt in (Wedge(slope=0.3), BeamHighpass(kpar0=0.02, kperp0=0.3, power=2.)):
+        lazy = box.apply_transfer_fn(box.to_k(dx), filt)
+        pend = box.binned_power_spectrum(delta_x=lazy.real, nbins=20, wait=False)
+        assert lazy._filtered is not None and not lazy.materialised and not lazy.spectrum.materialised
+        kc, pk, err = pend.result()
+        field = np.asarray(lazy.real)                                  # inverse of the stored filtered spectrum
+        # step by step: explicit spectrum, separate filter kernel, inverse, P(k) of the resulting field
+        slow = box.apply_transfer_fn(box.engine.fft_r2c(dx), filt)
+        want_field = np.asarray(slow).real
+        assert np.max(np.abs(field - want_field)) < 20 * tol * np.std(want_field)
+        kc2, pk2, err2 = box.binned_power_spectrum(delta_x=box.engine.upload(want_field, "real"), nbins=20)
+        m = ~np.isnan(pk2)
+        assert np.array_equal(kc, kc2) and np.array_equal(np.isnan(pk), np.isnan(pk2))
+        assert np.allclose(pk[m], pk2[m], rtol=tol, atol=tol * np.max(pk2[m]) * 1e-6)
+        assert np.allclose(err[m], err2[m], rtol=100 * tol, atol=tol * np.max(pk2[m]))
+
+
 @pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("f64", 1e-10)])
 @pytest.mark.parametrize("scale", [3e2, (1e2, 2e2, 4e2)])
 def test_velocity_in_real_space_regenerated_by_the_generator(prec, tol, scale):

@@ -16,9 +16,9 @@ def chain(sigma_nl):
     dx = box.realise_density()
     vz = box.to_real(box.realise_velocity()[2])
     ds = box.redshift_space_density(delta_x=dx, velocity_z=vz, sigma_nl=sigma_nl)
-    dk = eng.fft_r2c(ds)
+    dk = box.to_k(ds)                                       # pending forward transform
     filt = box.apply_transfer_fn(dk, wedge)                 # lazy (Hermitian field, filter even in k_par)
-    pk = box.binned_power_spectrum(delta_x=filt.real, nbins=20, wait=False)   # binned from dk * T directly
+    pk = box.binned_power_spectrum(delta_x=filt.real, nbins=20, wait=False)   # r2c, y, x(* T, store, bin)
     filt.ptr                                                # deliver the filtered field as well (3 FFT passes)
     return pk
 
