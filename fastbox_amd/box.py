@@ -66,10 +66,12 @@ class PendingSpectrum(object):
         self._eng, self._res, self._nb, self._kc, self._bf = engine, res, nbins, kc, boxfactor
         self._lnv, self._keep, self._out = ln_voxels, keepalive, None
         self._cnt = engine.bin_counts()
+        self._raw = None                       # the device record, delivered by the engine's batched fetch
+        engine.register_waiter(res, self)
 
     def result(self):
         if self._out is None:
-            s1, s2, esum = self._eng.fetch_results(self._res, self._nb)
+            s1, s2, esum = self._eng.fetch_results(self._res, self._nb, owner=self)
             if self._lnv:                      # transform of exp(d): rescale to exp(d)/mean - 1
                 mean = esum / self._lnv
                 s1, s2 = s1 / mean ** 2, s2 / mean ** 4

@@ -727,8 +727,12 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         kb[e] = order_bits(key);
         cell[e] = c;
         val[e] = d[m];
+#ifdef FB_EXPERIMENT_RSD_NOATOMIC
+        kmx[c] = kb[e]; kmn[c] = kb[e];
+#else
         atomicMax(&kmx[c], kb[e]);
         atomicMin(&kmn[c], kb[e]);
+#endif
     }
     __syncthreads();
 #pragma unroll

@@ -8,6 +8,7 @@ only copied to the host (as float64 / complex128, the reference's dtypes) when
 numpy touches it (``np.asarray``, indexing, ufuncs).
 """
 import ctypes
+import weakref
 
 import numpy as np
 from numpy.lib.mixins import NDArrayOperatorsMixin
@@ -34,6 +35,16 @@ class _Buffer(object):
         if pool is not None and self.ptr:
             pool.setdefault(self.nbytes, []).append(self.ptr)
             self.ptr = None
+
+
+class _ResultSlot(object):
+    """One (2*nbins+1)-double record of the engine's result ring on the device (bin sums of a queued
+    power spectrum).  All records queued since the last fetch come back in a single device-to-host copy."""
+
+    __slots__ = ("ptr", "serial")
+
+    def __init__(self, ptr, serial):
+        self.ptr, self.serial = ptr, serial
 
 
 class DeviceArray(NDArrayOperatorsMixin):
@@ -148,6 +159,12 @@ class Engine(object):
                        FULL: self.lib.fb_full_bytes(self._plan)}
         self._amp_dense = None
         self._bins_key = None
+        # ring of result records (see _ResultSlot): RES_SLOTS x RES_STRIDE doubles
+        self._res_dev = None
+        self._res_host = None
+        self._res_next = 0          # serial of the next record to hand out
+        self._res_fetched = 0       # records with serial < this are valid in _res_host (unless overwritten)
+        self._res_waiters = {}      # serial -> weakref of the PendingSpectrum that wants the record
 
     def close(self):
         if getattr(self, "_plan", None) is not None and self._plan:
@@ -156,6 +173,9 @@ class Engine(object):
                 for p in ptrs:
                     self.lib.fb_free(ctypes.c_void_p(p))
             self._pool = {}
+            if self._res_dev:
+                self.lib.fb_free(ctypes.c_void_p(self._res_dev))
+                self._res_dev = None
             self.lib.fb_plan_destroy(self._plan)
             self._plan = None
 
@@ -373,7 +393,7 @@ class Engine(object):
 
     def power_pending(self, pend, pre_exp=False):
         """Fused z pass (writes delta_x) + P(k) of (exp of) it.  Returns (results buffer, delta_x)."""
-        res = self._alloc_bytes((2 * self._nbins + 1) * 8)
+        res = self._result_slot()
         out = self.empty(REAL)
         _lib.call("fb_power_spectrum_pending", self._plan, pend.ptr, out.ptr, 1 if pre_exp else 0, res.ptr,
                   self.stream)
@@ -382,7 +402,7 @@ class Engine(object):
     def power_fused(self, real, pre_exp=False, keep_spectrum=False):
         """Asynchronous r2c + shell binning (cubic boxes).  Returns (results buffer, spectrum or None);
         results = [2*nbins+1] doubles on the device, fetched with `fetch_results`."""
-        res = self._alloc_bytes((2 * self._nbins + 1) * 8)
+        res = self._result_slot()
         work = self.empty(HALF) if keep_spectrum else self._scratch_half()
         _lib.call("fb_power_spectrum_device", self._plan, real.ptr, work.ptr, 1 if pre_exp else 0,
                   1 if keep_spectrum else 0, res.ptr, self.stream)
@@ -391,17 +411,65 @@ class Engine(object):
     def power_filtered(self, real, filt):
         """Asynchronous r2c of `real` whose last pass multiplies by the filter (kind, params), keeps the
         filtered spectrum and bins it.  Returns (results buffer, filtered half spectrum)."""
-        res = self._alloc_bytes((2 * self._nbins + 1) * 8)
+        res = self._result_slot()
         out = self.empty(HALF)
         prm = (ctypes.c_double * 4)(*[float(x) for x in filt[1]])
         _lib.call("fb_power_spectrum_filtered", self._plan, real.ptr, out.ptr, int(filt[0]), prm, None, res.ptr,
                   self.stream)
         return res, out
 
-    def fetch_results(self, res, nbins):
-        h = np.empty(2 * nbins + 1)
-        _lib.call("fb_memcpy_d2h", _ptr(h), res.ptr, h.nbytes, self.stream)
-        return h[0:2 * nbins:2].copy(), h[1:2 * nbins:2].copy(), h[2 * nbins]
+    RES_SLOTS, RES_STRIDE = 256, 2 * 256 + 1      # 256 = FB_MAX_BINS
+
+    def _result_slot(self):
+        """Next record of the result ring.  A record is overwritten RES_SLOTS hand-outs later; whatever is
+        still unfetched by then is brought to the host first."""
+        if self._res_dev is None:
+            p = ctypes.c_void_p()
+            _lib.call("fb_malloc", ctypes.byref(p), self.RES_SLOTS * self.RES_STRIDE * 8)
+            self._res_dev = p.value
+            self._res_host = np.zeros((self.RES_SLOTS, self.RES_STRIDE))
+        if self._res_next - self._res_fetched >= self.RES_SLOTS:
+            self._fetch_pending_results()
+        serial = self._res_next
+        self._res_next += 1
+        return _ResultSlot(self._res_dev + (serial % self.RES_SLOTS) * self.RES_STRIDE * 8, serial)
+
+    def _fetch_pending_results(self):
+        """One copy (two if the ring wraps) for every record queued since the last fetch; waits for the stream."""
+        lo, hi = self._res_fetched, self._res_next
+        a, b = lo % self.RES_SLOTS, hi % self.RES_SLOTS
+        spans = [(a, b)] if (a < b) else [(a, self.RES_SLOTS), (0, b)]
+        for x, y in spans:
+            if y > x:
+                _lib.call("fb_memcpy_d2h", _ptr(self._res_host[x:y]), self._res_dev + x * self.RES_STRIDE * 8,
+                          (y - x) * self.RES_STRIDE * 8, self.stream)
+        self._res_fetched = hi
+        for serial in range(lo, hi):             # hand every fetched record to whoever waits for it
+            w = self._res_waiters.pop(serial, None)
+            owner = w() if w is not None else None
+            if owner is not None:
+                owner._raw = self._res_host[serial % self.RES_SLOTS].copy()
+
+    def register_waiter(self, res, owner):
+        """`owner._raw` receives the record of `res` when it is fetched (possibly as part of a batch)."""
+        if isinstance(res, _ResultSlot):
+            self._res_waiters[res.serial] = weakref.ref(owner)
+
+    def fetch_results(self, res, nbins, owner=None):
+        if isinstance(res, _ResultSlot):
+            if owner is not None and getattr(owner, "_raw", None) is None:
+                self._fetch_pending_results()
+            h = owner._raw if owner is not None and getattr(owner, "_raw", None) is not None else None
+            if h is None:                          # no registered owner: read the ring's host mirror
+                if res.serial >= self._res_fetched:
+                    self._fetch_pending_results()
+                if self._res_next - res.serial > self.RES_SLOTS:
+                    raise RuntimeError("result record overwritten (not registered with register_waiter)")
+                h = self._res_host[res.serial % self.RES_SLOTS]
+        else:
+            h = np.empty(2 * nbins + 1)
+            _lib.call("fb_memcpy_d2h", _ptr(h), res.ptr, h.nbytes, self.stream)
+        return h[0:2 * nbins:2].copy(), h[1:2 * nbins:2].copy(), float(h[2 * nbins])
 
     def bin_counts(self):
         c = np.zeros(self._nbins)

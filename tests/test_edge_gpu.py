@@ -106,3 +106,16 @@ def test_full_size_properties(N):
     assert abs(total) < 1e-4                                       # <exp(d)/mean - 1> = 0
     box2 = _box(N, 1e3, precision="f32", rng="device", seed=3)
     assert box2.engine.sum_real(box2.realise_density(), squared=True) == box.engine.sum_real(dx, squared=True)
+
+
+def test_many_queued_spectra_come_back_in_batches():
+    """wait=False results live in a ring of device records fetched in one copy per batch; queue more than
+    the ring holds (256) before asking for any, read them out of order, compare with one-at-a-time."""
+    box = _box(32, 5e2, precision="f32", rng="device", seed=2)
+    pend = [box.binned_power_spectrum(delta_x=box.realise_density(), nbins=12, wait=False) for _ in range(300)]
+    order = list(range(299, -1, -7)) + list(range(300))
+    got = {i: pend[i].result() for i in order}
+    box2 = _box(32, 5e2, precision="f32", rng="device", seed=2)
+    for i in range(300):
+        want = box2.binned_power_spectrum(delta_x=box2.realise_density(), nbins=12)
+        assert np.array_equal(got[i][1], want[1], equal_nan=True) and np.array_equal(got[i][2], want[2], equal_nan=True), i

@@ -10,7 +10,9 @@ for V in ${KNOCKOUT_VARIANTS:-"" "-DFB_EXPERIMENT_NOAMP" "-DFB_EXPERIMENT_NOBM" 
     make -C fastbox_amd/csrc clean > /dev/null
     make -C fastbox_amd/csrc -j16 CXXFLAGS="$BASE $V" > /dev/null 2>&1
     echo "== variant: [$V]"
-    if [ -n "$KNOCKOUT_BENCH" ]; then
+    if [ -n "$KNOCKOUT_CONFIG3" ]; then
+        python tools/config3_bench.py 512 | grep -v amdgpu.ids | sed -n 1,2p
+    elif [ -n "$KNOCKOUT_BENCH" ]; then
         python bench.py --all-kernel-events --no-cpu-baseline --steps 40 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), d['kernel_ms_per_step'])"
     else
         python tools/pass_bench.py 512 | grep -E "gen|bin|plain, no"
