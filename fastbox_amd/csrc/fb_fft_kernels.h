@@ -468,11 +468,18 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 }
 
 // out[q] = sum_r partial[q][r], fixed order: one workgroup per value
+// (workgroup nvals, if launched: out[nvals] = sum of the single column partial2[nrows2], 0 if that is null --
+// the log-normal mean's block sums ride along with the bin sums in one launch)
 static __global__ __launch_bounds__(256) void k_sum_columns(const double* __restrict__ partial, long long nrows,
-                                                             int nvals, double* __restrict__ out) {
+                                                             int nvals, double* __restrict__ out,
+                                                             const double* __restrict__ partial2, long long nrows2) {
     __shared__ double sh[256];
     const int q = blockIdx.x;
     const double* src = partial + (size_t)q * nrows;
+    if (q == nvals) {
+        if (!partial2) { if (threadIdx.x == 0) out[q] = 0.0; return; }
+        src = partial2; nrows = nrows2;
+    }
     // fixed summation order (thread-strided, 8 independent chains so that the loads pipeline)
     double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long r = threadIdx.x;
