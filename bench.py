@@ -175,6 +175,14 @@ def main():
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
             "kernel_ms_total_per_step": round(total_ms / args.steps, 4),
         }
+        # whole step against the HBM roofline: SURVEY 8(d)'s byte model for this workload is 5.0 sweeps of
+        # N^3 complex values (this implementation moves 4.5: the z passes of realisation and estimate are one)
+        sweep = float(N) ** 3 * 2 * s
+        boxes_per_s = line["value"] / world            # per GPU
+        line["pipeline_roofline"] = {"bound": "hbm", "model_sweeps": 5.0, "moved_sweeps": 4.5,
+                                     "model_bytes_per_box": 5.0 * sweep,
+                                     "achieved": 5.0 * sweep * boxes_per_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": 5.0 * sweep * boxes_per_s / 1e9 / HBM_PEAK_GBS}
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_nsamp, args.nbins)
         else:

@@ -667,16 +667,17 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double* zg = reinterpret_cast<double*>(smem);                                   // [N]       shared by the block
-    u64* kmx = reinterpret_cast<u64*>(smem) + N + w * 2 * N;                        // [N] per wave: max of cell
-    u64* kmn = kmx + N;                                                             // [N] per wave: min of cell
-    T* vmx = reinterpret_cast<T*>(smem + sizeof(double) * N * (1 + 2 * FB_RSD_WAVES)) + w * 2 * N;
-    T* vmn = vmx + N;
+    // one key array and one value array per wave, used twice: first for the per-cell maxima (from which each
+    // lane takes the brackets below its cells into registers), then again for the minima.  Half the LDS of
+    // keeping both, and LDS is what limits the number of resident waves here.
+    u64* kex = reinterpret_cast<u64*>(smem) + N + w * N;                            // [N] per wave
+    T* vex = reinterpret_cast<T*>(smem + sizeof(double) * N * (1 + FB_RSD_WAVES)) + w * N;   // [N] per wave
     const long long los = (long long)blockIdx.x * FB_RSD_WAVES + w;                 // N*N % WAVES == 0
     const T* d = delta + los * N;
     const T* v = vz + los * N;
     for (int m = threadIdx.x; m < N; m += 64 * FB_RSD_WAVES) zg[m] = zgrid[m];
 #pragma unroll
-    for (int e = 0; e < E; ++e) { kmx[lane + 64 * e] = 0ull; kmn[lane + 64 * e] = ~0ull; }
+    for (int e = 0; e < E; ++e) kex[lane + 64 * e] = 0ull;
     __syncthreads();
     const double zmin = zg[0], zmax = zg[N - 1];
     const double len = zmax - zmin;
@@ -722,33 +723,31 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         const double key = r + zmin;
         int c = (int)((key - zmin) * inv_dz);
         c = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
-        for (int it = 0; it < N && c > 0 && key < zg[c]; ++it) --c;           // settle on z_c <= key < z_{c+1}
-        for (int it = 0; it < N && c < N - 1 && key >= zg[c + 1]; ++it) ++c;
+        // settle on z_c <= key < z_{c+1}: the estimate is off by at most one cell, so one step down and
+        // one step up without branches; the loops only run if that was not enough (never observed)
+        c -= (c > 0 && key < zg[c]) ? 1 : 0;
+        c += (c < N - 1 && key >= zg[c + 1]) ? 1 : 0;
+        if (__builtin_expect((c > 0 && key < zg[c]) || (c < N - 1 && key >= zg[c + 1]), 0)) {
+            for (int it = 0; it < N && c > 0 && key < zg[c]; ++it) --c;
+            for (int it = 0; it < N && c < N - 1 && key >= zg[c + 1]; ++it) ++c;
+        }
         kb[e] = order_bits(key);
         cell[e] = c;
         val[e] = d[m];
-#ifdef FB_EXPERIMENT_RSD_NOATOMIC
-        kmx[c] = kb[e]; kmn[c] = kb[e];
-#else
-        atomicMax(&kmx[c], kb[e]);
-        atomicMin(&kmn[c], kb[e]);
-#endif
+        atomicMax(&kex[c], kb[e]);
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (kmx[cell[e]] == kb[e]) vmx[cell[e]] = val[e];
-        if (kmn[cell[e]] == kb[e]) vmn[cell[e]] = val[e];
-    }
+    for (int e = 0; e < E; ++e)
+        if (kex[cell[e]] == kb[e]) vex[cell[e]] = val[e];
     const double fill = 0.5 * ((double)d[0] + (double)d[N - 1]);
     __syncthreads();
     // nearest non-empty cell strictly below / at-or-above each of this lane's cells
-    u64 cmx[E], cmn[E];
+    u64 cmx[E];
     int last = -1, first = N;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        cmx[e] = kmx[lane * E + e];
-        cmn[e] = kmn[lane * E + e];
+        cmx[e] = kex[lane * E + e];
         if (cmx[e] != 0ull) { last = lane * E + e; if (first == N) first = lane * E + e; }
     }
     int below = last, above = first;                  // inclusive scans over lanes: max from the left, min from the right
@@ -768,6 +767,33 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
 #pragma unroll
         for (int e = E - 1; e >= 0; --e) { if (cmx[e] != 0ull) a = lane * E + e; ab[e] = a; }
     }
+    // lower bracket of every cell of this lane: (largest key, its value) of the nearest occupied cell below
+    u64 pk[E];
+    T pv[E];
+    int rbv[E];
+    {
+        int rb = run_below;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            rbv[e] = rb;
+            const int q = rb < 0 ? 0 : rb;
+            pk[e] = kex[q];
+            pv[e] = vex[q];
+            if (cmx[e] != 0ull) rb = lane * E + e;
+        }
+    }
+    __syncthreads();
+    // second use of the arrays: per-cell minima
+#pragma unroll
+    for (int e = 0; e < E; ++e) kex[lane + 64 * e] = ~0ull;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) atomicMin(&kex[cell[e]], kb[e]);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (kex[cell[e]] == kb[e]) vex[cell[e]] = val[e];
+    __syncthreads();
     T y_out[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -775,18 +801,27 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         const int c = lane * E + e;
         const double x = zg[c];
         const bool filled = cmx[e] != 0ull;
+        const int run_below = rbv[e];
+        const u64 cmn_e = kex[c];
         double y;
-        if (filled && order_value(cmn[e]) == x) y = (double)vmn[c];
-        else if (run_below < 0 || ab[e] >= N) y = fill;
-        else {
-            const double kj = order_value(kmx[run_below]), vj = (double)vmx[run_below];
-            const double kn = order_value(kmn[ab[e]]), vn = (double)vmn[ab[e]];
-            if constexpr (sizeof(T) == 4) {
-                // differences in fp64 (close keys cancel), the quotient in fp32
-                const float w = (float)(x - kj) / (float)(kn - kj);
-                y = (double)(vmx[run_below] + (vmn[ab[e]] - vmx[run_below]) * w);
-                if (y != y) y = vj == vn ? vj : y;
-            } else {
+        if constexpr (sizeof(T) == 4) {
+            // branch-free: bracket indices clamped into range, the three cases selected at the end
+            const bool exact = filled && order_value(cmn_e) == x;
+            const bool nofill = run_below >= 0 && ab[e] < N;
+            const int ra = ab[e] < N ? ab[e] : N - 1;
+            const double kj = order_value(pk[e]), kn = order_value(kex[ra]);
+            const float vj = pv[e], vn = vex[ra];
+            // differences in fp64 (close keys cancel), the quotient in fp32
+            const float w = (float)(x - kj) * __builtin_amdgcn_rcpf((float)(kn - kj));
+            float yi = vj + (vn - vj) * w;
+            yi = (yi != yi && vj == vn) ? vj : yi;
+            y = exact ? (double)vex[c] : (nofill ? (double)yi : fill);
+        } else {
+            if (filled && order_value(cmn_e) == x) y = (double)vex[c];
+            else if (run_below < 0 || ab[e] >= N) y = fill;
+            else {
+                const double kj = order_value(pk[e]), vj = (double)pv[e];
+                const double kn = order_value(kex[ab[e]]), vn = (double)vex[ab[e]];
                 const double slope = (vn - vj) / (kn - kj);
                 y = slope * (x - kj) + vj;
                 if (y != y) {
@@ -796,7 +831,6 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
             }
         }
         y_out[e] = (T)y;
-        if (filled) run_below = c;
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) out[los * N + lane * E + e] = y_out[e];
