@@ -58,3 +58,38 @@ def load_reference_box():
         else:
             sys.modules["pyccl"] = had
     return mod
+
+
+def load_reference_module(relpath, name):
+    """Load another single-file module of the reference package (e.g. 'fastbox/noise.py') with the same
+    stand-in pyccl.  Only modules whose imports are available here work (noise.py, foregrounds.py: numpy,
+    scipy.ndimage, pylab; healpy is optional there)."""
+    path = os.path.join("/root/reference", relpath)
+    if not os.path.exists(path):
+        raise RuntimeError("reference sources are not present on this machine")
+    sys.dont_write_bytecode = True
+    import warnings
+    import matplotlib
+    matplotlib.use("Agg")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    from fastbox_amd import cosmology as cosmo_mod
+    shim = types.ModuleType("pyccl")
+    for nm in ("Cosmology", "nonlin_matter_power", "linear_matter_power", "h_over_h0", "growth_rate",
+               "growth_factor", "comoving_angular_distance"):
+        setattr(shim, nm, getattr(cosmo_mod, nm))
+    had = sys.modules.get("pyccl")
+    sys.modules["pyccl"] = shim
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            spec = importlib.util.spec_from_file_location(name, path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+    finally:
+        if had is None:
+            sys.modules.pop("pyccl", None)
+        else:
+            sys.modules["pyccl"] = had
+    return mod

@@ -107,3 +107,37 @@ def test_oracle_against_live_reference():
     ora_pk = bo.binned_power_spectrum(geo, dk, nbins=30)
     for a, b in zip(ref_pk, ora_pk):
         assert _same(a, b)
+
+
+# ---- noise / foreground steps: oracle/sky_oracle.py against vectors captured from the reference
+@pytest.mark.parametrize("name", ["sky_n16", "sky_n32"])
+def test_sky_oracle_reproduces_reference_vectors(golden_dir, name):
+    from oracle import sky_oracle as so
+    from fastbox_amd import cosmology
+    g = _load(golden_dir, name)
+    N, z, seed = int(g["N"]), float(g["redshift"]), int(g["seed"])
+    geo = bo.box_geometry(tuple(g["box_scale"]), N)
+    a = 1. / (1. + z)
+    cosmo = standin.cosmology()
+    freqs = bo.freq_array(geo, a, 1420.405752, standin.hubble(cosmo, a))
+    r = cosmology.comoving_angular_distance(cosmo, a)
+    ang_x, ang_y = bo.pixel_array(geo, r)
+    assert _same(freqs, g["freqs"]) and _same(ang_x, g["ang_x"])
+    pix = ang_x[1] - ang_x[0]
+    rng = np.random.RandomState(seed + 1)
+    fg_map = so.foreground_amp(geo, r, 57., 1.1, 10., sigma_pix=4. / pix, rng=rng)
+    alpha = so.spectral_index(N, 2.07, 0.0002, 15. / pix, rng=rng)
+    assert _same(fg_map, g["fg_map"]) and _same(alpha, g["alpha"])
+    assert _same(so.construct_cube(fg_map, alpha, freqs, 130.), g["fg_cube"])
+    raw = so.foreground_amp(geo, r, 57., 1.1, 10., rng=np.random.RandomState(seed + 2))
+    assert _same(raw, g["fg_map_raw"]) and _same(so.construct_cube(raw, 2.1, freqs, 130.), g["fg_cube_scalar"])
+    sig = so.radiometer_sigma(freqs, ang_x, 18., 2., 1., 64)
+    assert _same(so.radiometer_noise((N, N, N), sig, np.random.RandomState(seed + 3)), g["noise_cube"])
+    # the separable kernel the device smoothing uses is scipy's
+    w, rad = so.gaussian_weights(4. / pix)
+    import scipy.ndimage
+    x = np.random.RandomState(1).normal(size=(N, N))
+    mine = x
+    for ax in (0, 1):
+        mine = sum(w[j] * np.roll(mine, rad - j, axis=ax) for j in range(2 * rad + 1))
+    assert np.max(np.abs(mine - scipy.ndimage.gaussian_filter(x, 4. / pix, mode="wrap"))) < 1e-13
