@@ -59,6 +59,11 @@ SIGNATURES = {
     "fb_power_spectrum_pending": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "fb_power_spectrum_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fb_bin_counts": (c_int, [c_void_p, P_double]),
+    "fb_sky_realise_map": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_double, c_void_p, c_void_p, c_void_p]),
+    "fb_sky_normal_map": (c_int, [c_void_p, c_void_p, c_u64, c_double, c_double, c_void_p, c_void_p]),
+    "fb_sky_gaussian_filter": (c_int, [c_void_p, c_void_p, c_void_p, P_double, c_int, c_void_p]),
+    "fb_sky_foreground_cube": (c_int, [c_void_p, c_void_p, c_void_p, c_double, P_double, c_void_p, c_void_p]),
+    "fb_sky_noise_cube": (c_int, [c_void_p, P_double, c_void_p, c_u64, c_void_p, c_void_p]),
     "fb_slab_half_bytes": (c_i64, [c_void_p, c_int]),
     "fb_slab_kspace_bytes": (c_i64, [c_void_p, c_int]),
     "fb_slab_forward_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -316,6 +316,47 @@ int fb_bin_counts(fb_plan* p, double* count) {
     return FB_OK;
 }
 
+// ---- foreground maps / cube, radiometer noise (the steps after the density-field path) -------------------------
+int fb_sky_realise_map(fb_plan* p, const void* amp2d, const void* re, const void* im, uint64_t seed, double monopole,
+                       void* work_cplx, void* map_out, void* stream) {
+    FB_REQUIRE(p && amp2d && work_cplx && map_out, "null pointer");
+    FB_REQUIRE((re == nullptr) == (im == nullptr), "give both re and im, or neither (device generator)");
+    hipStream_t s = (hipStream_t)stream;
+    int r = FB_DISPATCH(p, fbi_sky_colour_map_f32(p, amp2d, re, im, seed, work_cplx, s),
+                        fbi_sky_colour_map_f64(p, amp2d, re, im, seed, work_cplx, s));
+    if (r) return r;
+    const double scale = 1.0 / ((double)p->N * p->N);
+    r = FB_DISPATCH(p, fbi_fft2d_c2c_f32(p, work_cplx, +1, scale, s), fbi_fft2d_c2c_f64(p, work_cplx, +1, scale, s));
+    if (r) return r;
+    return FB_DISPATCH(p, fbi_sky_real_plus_f32(p, work_cplx, map_out, monopole, s),
+                       fbi_sky_real_plus_f64(p, work_cplx, map_out, monopole, s));
+}
+int fb_sky_normal_map(fb_plan* p, const void* unit, uint64_t seed, double mean, double std, void* map_out, void* stream) {
+    FB_REQUIRE(p && map_out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_sky_normal_map_f32(p, unit, seed, mean, std, map_out, s),
+                       fbi_sky_normal_map_f64(p, unit, seed, mean, std, map_out, s));
+}
+int fb_sky_gaussian_filter(fb_plan* p, void* map_inout, void* tmp, const double* weights, int radius, void* stream) {
+    FB_REQUIRE(p && map_inout && tmp && weights, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_sky_gaussian_f32(p, map_inout, tmp, weights, radius, s),
+                       fbi_sky_gaussian_f64(p, map_inout, tmp, weights, radius, s));
+}
+int fb_sky_foreground_cube(fb_plan* p, const void* amps, const void* alpha, double alpha_scalar, const double* ratio,
+                           void* cube_out, void* stream) {
+    FB_REQUIRE(p && amps && ratio && cube_out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_sky_fg_cube_f32(p, amps, alpha, alpha_scalar, ratio, cube_out, s),
+                       fbi_sky_fg_cube_f64(p, amps, alpha, alpha_scalar, ratio, cube_out, s));
+}
+int fb_sky_noise_cube(fb_plan* p, const double* sigma, const void* unit, uint64_t seed, void* cube_out, void* stream) {
+    FB_REQUIRE(p && sigma && cube_out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_sky_noise_cube_f32(p, sigma, unit, seed, cube_out, s),
+                       fbi_sky_noise_cube_f64(p, sigma, unit, seed, cube_out, s));
+}
+
 // ---- slab-decomposed transforms -------------------------------------------------------------------
 #define FB_SLAB_CHECK(p, nparts) \
     FB_REQUIRE((p), "null pointer"); \

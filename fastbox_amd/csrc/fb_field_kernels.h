@@ -836,4 +836,86 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
     for (int e = 0; e < E; ++e) out[los * N + lane * E + e] = y_out[e];
 }
 
+// ---- the steps after the density-field path: foreground maps / cube, radiometer noise ------
+// 2-D maps are T[N][N] over (x, y); cubes T[N][N][N] with the frequency axis last (fastest), as box.py's fields.
+// RNG streams of the counter generator: 1 line-of-sight noise, 2 foreground map, 3 spectral index, 4 noise cube.
+
+// foregrounds.py:99-103: fg_k = (re + i im) sqrt(C_ell); amp2d holds sqrt(C_ell) with the zero mode already 0
+template <typename T>
+__global__ void k_sky_colour_map(const T* __restrict__ amp2d, const T* __restrict__ re, const T* __restrict__ im,
+                                 cx<T>* __restrict__ out, int n2, RngKey key) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    T a, b;
+    if (re) { a = re[q]; b = im[q]; }
+    else {
+        T g0, g1, g2, g3;
+        mode_noise_pair<T>((unsigned long long)(q >> 1), 2u, key, g0, g1, g2, g3);
+        a = (q & 1) ? g2 : g0; b = (q & 1) ? g3 : g1;
+    }
+    const T A = amp2d[q];
+    out[q] = cx<T>{A * a, A * b};
+}
+// foregrounds.py:107: fg_x = ifftn(fg_k).real + monopole
+template <typename T>
+__global__ void k_sky_real_plus(const cx<T>* __restrict__ in, T* __restrict__ out, int n2, T add) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n2) out[q] = in[q].x + add;
+}
+// foregrounds.py:137-138: alpha = normal(mean, std)
+template <typename T>
+__global__ void k_sky_normal_map(const T* __restrict__ unit, T* __restrict__ out, int n2, double mean, double std, RngKey key) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    T n;
+    if (unit) n = unit[q];
+    else n = stream_noise_at<T>((unsigned long long)q, 3u, key);
+    out[q] = (T)(mean + std * (double)n);
+}
+// scipy.ndimage.gaussian_filter(mode='wrap') along one axis: out[i] = sum_j w[j] in[(i + j - r) mod N]
+// (axis 0: stride N between neighbours, axis 1: stride 1); fp64 accumulation, weights as scipy forms them
+template <typename T>
+__global__ void k_sky_gauss_axis(const T* __restrict__ in, T* __restrict__ out, const double* __restrict__ w,
+                                 int radius, int N, int axis) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N * N) return;
+    const int x = q / N, y = q % N;
+    const int i = axis == 0 ? x : y;
+    double acc = 0.0;
+    for (int j = 0; j <= 2 * radius; ++j) {
+        int k = (i + j - radius) % N;
+        if (k < 0) k += N;
+        acc += w[j] * (double)(axis == 0 ? in[(long long)k * N + y] : in[(long long)x * N + k]);
+    }
+    out[q] = (T)acc;
+}
+// foregrounds.py:165-175: cube = amps[x,y] (freqs[z]/freq_ref)^alpha[x,y]; lr[z] = log2(freqs[z]/freq_ref)
+template <typename T>
+__global__ __launch_bounds__(256) void k_sky_fg_cube(const T* __restrict__ amps, const T* __restrict__ alpha,
+                                                     double alpha_scalar, const double* __restrict__ ratio,
+                                                     T* __restrict__ out, int N) {
+    const long long row = blockIdx.x;                                   // (x, y)
+    const T a = amps[row];
+    const double al = alpha ? (double)alpha[row] : alpha_scalar;
+    for (int z = threadIdx.x; z < N; z += blockDim.x) {
+        T v;
+        if constexpr (sizeof(T) == 4) v = a * __builtin_amdgcn_exp2f((float)al * (float)ratio[N + z]);   // 2^(alpha lr)
+        else v = (T)((double)a * pow(ratio[z], al));
+        out[row * N + z] = v;
+    }
+}
+// noise.py:72-74: unit normals scaled per frequency channel; device RNG: 4 consecutive channels per call
+template <typename T>
+__global__ __launch_bounds__(256) void k_sky_noise_cube(const T* __restrict__ unit, const double* __restrict__ sigma,
+                                                        T* __restrict__ out, long long n4, int N, RngKey key) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // group of 4 consecutive voxels
+    if (q >= n4) return;
+    T g[4];
+    if (unit) { for (int u = 0; u < 4; ++u) g[u] = unit[4 * q + u]; }
+    else mode_noise_pair<T>((unsigned long long)q, 4u, key, g[0], g[1], g[2], g[3]);
+    const int z0 = (int)((4 * q) % N);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) out[4 * q + u] = (T)((double)g[u] * sigma[z0 + u]);
+}
+
 }  // namespace fb

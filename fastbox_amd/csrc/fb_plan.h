@@ -104,6 +104,17 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_colour_device_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* out, hipStream_t s); \
     int fbi_power_filtered_##sfx(fb_plan* p, const void* real_in, void* filtered_half, int kind, const double* prm, \
                                  const void* table, double* results, hipStream_t s); \
+    int fbi_fft2d_c2c_##sfx(fb_plan* p, void* data, int sign, double scale, hipStream_t s); \
+    int fbi_sky_colour_map_##sfx(fb_plan* p, const void* amp2d, const void* re, const void* im, uint64_t seed, \
+                                 void* out, hipStream_t s); \
+    int fbi_sky_real_plus_##sfx(fb_plan* p, const void* in, void* out, double add, hipStream_t s); \
+    int fbi_sky_normal_map_##sfx(fb_plan* p, const void* unit, uint64_t seed, double mean, double std, void* out, \
+                                 hipStream_t s); \
+    int fbi_sky_gaussian_##sfx(fb_plan* p, void* map, void* tmp, const double* weights, int radius, hipStream_t s); \
+    int fbi_sky_fg_cube_##sfx(fb_plan* p, const void* amps, const void* alpha, double alpha_scalar, \
+                              const double* ratio, void* out, hipStream_t s); \
+    int fbi_sky_noise_cube_##sfx(fb_plan* p, const double* sigma, const void* unit, uint64_t seed, void* out, \
+                                 hipStream_t s); \
     int fbi_bin_power_##sfx(fb_plan* p, const void* spec, int layout, int filter_kind, const double* prm, \
                             const void* table, double* sums_dev, hipStream_t s); \
     int fbi_apply_filter_##sfx(fb_plan* p, const void* in, void* out, int layout, int kind, const double* prm, \

@@ -116,11 +116,15 @@ __device__ __forceinline__ void mode_noise_pair(unsigned long long idx, uint32_t
 // Small-scale velocity noise of the redshift-space remap (stream 1): element idx of the (N,N,N)
 // grid takes output idx & 3 of call idx >> 2, so four consecutive line-of-sight cells share one call.
 template <typename T>
-__device__ __forceinline__ T los_noise_at(unsigned long long idx, const RngKey& key) {
+__device__ __forceinline__ T stream_noise_at(unsigned long long idx, uint32_t stream, const RngKey& key) {
     T g0, g1, g2, g3;
-    mode_noise_pair<T>(idx >> 2, 1u, key, g0, g1, g2, g3);
+    mode_noise_pair<T>(idx >> 2, stream, key, g0, g1, g2, g3);
     const int r = (int)(idx & 3ull);
     return r == 0 ? g0 : (r == 1 ? g1 : (r == 2 ? g2 : g3));
+}
+template <typename T>
+__device__ __forceinline__ T los_noise_at(unsigned long long idx, const RngKey& key) {
+    return stream_noise_at<T>(idx, 1u, key);
 }
 
 }  // namespace fb

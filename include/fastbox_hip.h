@@ -179,6 +179,28 @@ int fb_profile_select(fb_plan* plan, unsigned mask);   /* bit i = bracket class 
 int fb_profile_start(fb_plan* plan);
 int fb_profile_stop(fb_plan* plan, void* stream, double* ms, int64_t* launches, int ncat);
 
+/* ---- the steps after the density-field path: foregrounds (fastbox/foregrounds.py:48-175) and radiometer
+ * noise (fastbox/noise.py:25-75).  2-D maps are T[N][N] over (x, y); cubes T[N][N][N], frequency axis last. ---- */
+/* realise_foreground_amp (:99-107): map_out = Re ifft2((re + i im) amp2d) + monopole.  amp2d = sqrt(C_ell) per
+ * 2-D mode with the k_perp = 0 entry 0 (:83-103, evaluated on the host); re, im = the reference's np.random.normal
+ * draws as device maps, or both NULL for the counter generator (stream 2).  work_cplx: complex T[N][N] scratch. */
+int fb_sky_realise_map(fb_plan* plan, const void* amp2d, const void* re, const void* im, uint64_t seed,
+                       double monopole, void* work_cplx, void* map_out, void* stream);
+/* realise_spectral_index (:137-138): map_out = mean + std n; n = `unit` (device map of N(0,1) draws) or generator */
+int fb_sky_normal_map(fb_plan* plan, const void* unit, uint64_t seed, double mean, double std, void* map_out,
+                      void* stream);
+/* scipy.ndimage.gaussian_filter(map, sigma, mode='wrap') (:113, :144) with the 2*radius+1 HOST weights scipy
+ * forms (exp(-x^2 / 2 sigma^2) normalised, radius = int(4 sigma + 0.5)); in place, tmp = T[N][N] scratch           */
+int fb_sky_gaussian_filter(fb_plan* plan, void* map_inout, void* tmp, const double* weights, int radius, void* stream);
+/* construct_cube (:165-175): cube = amps[x,y] * ratio[z] ** alpha[x,y] (alpha NULL: ** alpha_scalar);
+ * ratio = freqs / freq_ref, HOST double[N]                                                                      */
+int fb_sky_foreground_cube(fb_plan* plan, const void* amps, const void* alpha, double alpha_scalar,
+                           const double* ratio, void* cube_out, void* stream);
+/* realise_radiometer_noise (noise.py:72-74): cube = n[x,y,z] * sigma[z]; sigma = HOST double[N] (radiometer rms per
+ * channel, :53-69 on the host); n = `unit` (device cube of the reference's draws) or the generator (stream 4)      */
+int fb_sky_noise_cube(fb_plan* plan, const double* sigma, const void* unit, uint64_t seed, void* cube_out,
+                      void* stream);
+
 /* ---- slab-decomposed 3-D FFT for one box spread over `nparts` GPUs (one process per GPU) ---------
  * Rank `part` owns x-planes [part*N/nparts, ...) of real fields (T[N/nparts][N][N]) and, in k space,
  * k_y rows [part*N/nparts, ...) of every x-plane: kslab = complex<T>[N][N/nparts][pitch].
