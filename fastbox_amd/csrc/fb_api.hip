@@ -316,6 +316,17 @@ int fb_bin_counts(fb_plan* p, double* count) {
     return FB_OK;
 }
 
+int fb_real_axpby(fb_plan* p, const void* x, const void* y, void* out, double a, double b, double c, void* stream) {
+    FB_REQUIRE(p && x && out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_real_axpby_f32(p, x, y, out, a, b, c, 0, s), fbi_real_axpby_f64(p, x, y, out, a, b, c, 0, s));
+}
+int fb_real_multiply(fb_plan* p, const void* x, const void* y, void* out, void* stream) {
+    FB_REQUIRE(p && x && y && out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_real_axpby_f32(p, x, y, out, 0, 0, 0, 1, s), fbi_real_axpby_f64(p, x, y, out, 0, 0, 0, 1, s));
+}
+
 // ---- foreground maps / cube, radiometer noise (the steps after the density-field path) -------------------------
 int fb_sky_realise_map(fb_plan* p, const void* amp2d, const void* re, const void* im, uint64_t seed, double monopole,
                        void* work_cplx, void* map_out, void* stream) {

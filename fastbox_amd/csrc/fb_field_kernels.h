@@ -297,6 +297,20 @@ __global__ void k_affine(T* __restrict__ x, long long n, T a, T b) {
         x[q] = x[q] * a + b;
 }
 
+// out = a x + b y + c over a real cube (y may be null): the caller-side arithmetic of the end-to-end flow
+// (examples/example_endtoend.py:47, :75, :86: T_b (1 + delta), cube + foregrounds, += noise) kept on the device
+template <typename T>
+__global__ void k_axpby(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ out, long long n, T a, T b, T c) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x)
+        out[q] = y ? x[q] * a + y[q] * b + c : x[q] * a + c;
+}
+// out = x * y (element-wise)
+template <typename T>
+__global__ void k_mul_real(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ out, long long n) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x)
+        out[q] = x[q] * y[q];
+}
+
 // ---- k-space multipliers ---------------------------------------------------------------------------
 // box.py:374-379 (apply_transfer_fn) and :651-653 (smooth_field).
 enum { FILT_TABLE = 0, FILT_BEAM_HIGHPASS = 1, FILT_WEDGE = 2, FILT_TOPHAT = 3 };

@@ -104,6 +104,8 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_colour_device_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* out, hipStream_t s); \
     int fbi_power_filtered_##sfx(fb_plan* p, const void* real_in, void* filtered_half, int kind, const double* prm, \
                                  const void* table, double* results, hipStream_t s); \
+    int fbi_real_axpby_##sfx(fb_plan* p, const void* x, const void* y, void* out, double a, double b, double c, \
+                             int mul, hipStream_t s); \
     int fbi_fft2d_c2c_##sfx(fb_plan* p, void* data, int sign, double scale, hipStream_t s); \
     int fbi_sky_colour_map_##sfx(fb_plan* p, const void* amp2d, const void* re, const void* im, uint64_t seed, \
                                  void* out, hipStream_t s); \

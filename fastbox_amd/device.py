@@ -95,11 +95,49 @@ class DeviceArray(NDArrayOperatorsMixin):
             return h.astype(dtype)
         return h
 
+    def _device_arith(self, ufunc, inputs):
+        """+, -, * between real cubes of one engine, or a real cube and a Python scalar, without leaving the GPU
+        (the arithmetic callers of the reference write between the steps of a pipeline).  None: not handled."""
+        if ufunc not in (np.add, np.subtract, np.multiply, np.negative) or not all(
+                (isinstance(x, DeviceArray) and x.kind == REAL and not x._as_complex and x.engine is self.engine)
+                or isinstance(x, (int, float, np.floating, np.integer)) for x in inputs):
+            return None
+        eng = self.engine
+        dev = [x for x in inputs if isinstance(x, DeviceArray)]
+        if ufunc is np.negative:
+            return eng.axpby(inputs[0], None, -1.0, 0.0, 0.0)
+        x, y = inputs
+        if len(dev) == 2:
+            if ufunc is np.multiply:
+                return eng.multiply(x, y)
+            return eng.axpby(x, y, 1.0, 1.0 if ufunc is np.add else -1.0, 0.0)
+        s, d, first = (float(y), x, True) if isinstance(x, DeviceArray) else (float(x), y, False)
+        if ufunc is np.multiply:
+            return eng.axpby(d, None, s, 0.0, 0.0)
+        if ufunc is np.add:
+            return eng.axpby(d, None, 1.0, 0.0, s)
+        return eng.axpby(d, None, 1.0, 0.0, -s) if first else eng.axpby(d, None, -1.0, 0.0, s)     # d - s, s - d
+
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if method == "__call__" and not kwargs:
+            out = self._device_arith(ufunc, inputs)
+            if out is not None:
+                return out
         args = [x.host() if isinstance(x, DeviceArray) else x for x in inputs]
         if "out" in kwargs:
             return NotImplemented
         return getattr(ufunc, method)(*args, **kwargs)
+
+    # `cube += other` rebinds the name to a new device cube (device fields are immutable snapshots; other
+    # references to the old cube keep its values)
+    def __iadd__(self, other):
+        return self + other
+
+    def __isub__(self, other):
+        return self - other
+
+    def __imul__(self, other):
+        return self * other
 
     def __getitem__(self, idx):
         return self.host()[idx]
@@ -331,6 +369,19 @@ class Engine(object):
         _lib.call("fb_apply_filter", self._plan, spec.ptr, out.ptr, 1 if spec.kind == HALF else 0, int(kind), prm,
                   table.ptr if table is not None else None, self.stream)
         out.invalidate()
+        return out
+
+    def axpby(self, x, y, a, b, c):
+        """a x + b y + c over real cubes (y may be None), on the device."""
+        x.ptr
+        out = self.empty(REAL)
+        _lib.call("fb_real_axpby", self._plan, x.ptr, y.ptr if y is not None else None, out.ptr, float(a), float(b),
+                  float(c), self.stream)
+        return out
+
+    def multiply(self, x, y):
+        out = self.empty(REAL)
+        _lib.call("fb_real_multiply", self._plan, x.ptr, y.ptr, out.ptr, self.stream)
         return out
 
     def velocity_k(self, spec, comp, fac):

@@ -179,6 +179,11 @@ int fb_profile_select(fb_plan* plan, unsigned mask);   /* bit i = bracket class 
 int fb_profile_start(fb_plan* plan);
 int fb_profile_stop(fb_plan* plan, void* stream, double* ms, int64_t* launches, int ncat);
 
+/* element-wise arithmetic on real cubes T[N][N][N], the callers' own numpy expressions between the steps
+ * (examples/example_endtoend.py:47, :75, :86): out = a x + b y + c (y may be NULL); out = x * y.  out may alias. */
+int fb_real_axpby(fb_plan* plan, const void* x, const void* y, void* out, double a, double b, double c, void* stream);
+int fb_real_multiply(fb_plan* plan, const void* x, const void* y, void* out, void* stream);
+
 /* ---- the steps after the density-field path: foregrounds (fastbox/foregrounds.py:48-175) and radiometer
  * noise (fastbox/noise.py:25-75).  2-D maps are T[N][N] over (x, y); cubes T[N][N][N], frequency axis last. ---- */
 /* realise_foreground_amp (:99-107): map_out = Re ifft2((re + i im) amp2d) + monopole.  amp2d = sqrt(C_ell) per

@@ -78,3 +78,24 @@ def test_device_generator_sky_statistics(precision):
     box2 = CosmoBox(cosmo=standin.DEFAULT_COSMO, box_scale=2e3, nsamp=N, redshift=0.8, realise_now=False,
                     precision=precision, rng="device", seed=4)
     assert np.array_equal(np.asarray(NoiseModel(box2).realise_radiometer_noise(Tinst=18., tp=2., fov=1., Ndish=64)), cube)
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-6), ("f64", 1e-14)])
+def test_cube_arithmetic_stays_on_the_device(precision, tol):
+    """The numpy expressions callers write between the steps (example_endtoend.py:47, :75, :86) on DeviceArrays."""
+    from fastbox_amd import CosmoBox, DeviceArray
+    N = 32
+    box = CosmoBox(cosmo=standin.DEFAULT_COSMO, box_scale=1e3, nsamp=N, realise_now=False, precision=precision,
+                   rng="device", seed=1)
+    a = box.realise_density()
+    b = box.lognormal(box.realise_density())
+    ha, hb = np.asarray(a), np.asarray(b)
+    cases = [(a + b, ha + hb), (a - b, ha - hb), (a * b, ha * hb), (0.3 * (1. + a), 0.3 * (1. + ha)), (a * 2, ha * 2),
+             (2. - a, 2. - ha), (a - 2., ha - 2.), (-a, -ha)]
+    for got, want in cases:
+        assert isinstance(got, DeviceArray) and got.kind == "real"
+        assert np.max(np.abs(np.asarray(got) - want)) <= tol * np.max(np.abs(want))
+    assert isinstance(a + ha, np.ndarray)                       # mixed with a host array: numpy semantics
+    cube = a
+    cube += b                                                   # __iadd__ falls back to a new device cube
+    assert isinstance(cube, DeviceArray) and np.max(np.abs(np.asarray(cube) - (ha + hb))) <= tol * np.max(np.abs(ha + hb))
