@@ -61,6 +61,9 @@ SIGNATURES = {
     "fb_bin_counts": (c_int, [c_void_p, P_double]),
     "fb_real_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_void_p]),
     "fb_real_multiply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fb_channel_means": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fb_channel_covariance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fb_pca_clean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "fb_sky_realise_map": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_double, c_void_p, c_void_p, c_void_p]),
     "fb_sky_normal_map": (c_int, [c_void_p, c_void_p, c_u64, c_double, c_double, c_void_p, c_void_p]),
     "fb_sky_gaussian_filter": (c_int, [c_void_p, c_void_p, c_void_p, P_double, c_int, c_void_p]),

@@ -96,7 +96,7 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
 
 int fb_plan_destroy(fb_plan* p) {
     if (!p) return FB_OK;
-    void* ptrs[] = {p->tw, p->axis2, p->ksc, p->kpar, p->zgrid, p->amp_shell, p->amp_sym, p->kperp_tab, p->bins, p->thr, p->counts,
+    void* ptrs[] = {p->tw, p->axis2, p->ksc, p->kpar, p->zgrid, p->amp_shell, p->amp_sym, p->kperp_tab, p->pca_work, p->bins, p->thr, p->counts,
                     p->partials, p->scratch, p->bin_partials, p->exp_partials};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     delete p;
@@ -325,6 +325,25 @@ int fb_real_multiply(fb_plan* p, const void* x, const void* y, void* out, void* 
     FB_REQUIRE(p && x && y && out, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_real_axpby_f32(p, x, y, out, 0, 0, 0, 1, s), fbi_real_axpby_f64(p, x, y, out, 0, 0, 0, 1, s));
+}
+
+// ---- PCA foreground cleaning (fastbox/filters.py:93-183) -----------------------------------------------------
+int fb_channel_means(fb_plan* p, const void* cube, double* mean_dev, void* stream) {
+    FB_REQUIRE(p && cube && mean_dev, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_channel_means_f32(p, cube, mean_dev, s), fbi_channel_means_f64(p, cube, mean_dev, s));
+}
+int fb_channel_covariance(fb_plan* p, const void* cube, const double* mean_dev, double* cov_dev, void* stream) {
+    FB_REQUIRE(p && cube && mean_dev && cov_dev, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_channel_cov_f32(p, cube, mean_dev, cov_dev, s), fbi_channel_cov_f64(p, cube, mean_dev, cov_dev, s));
+}
+int fb_pca_clean(fb_plan* p, const void* cube, const double* mean_dev, const double* modes_dev, int nmodes, void* cube_out,
+                 double* amps_dev, void* stream) {
+    FB_REQUIRE(p && cube && mean_dev && cube_out && (modes_dev || nmodes == 0), "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_pca_clean_f32(p, cube, mean_dev, modes_dev, nmodes, cube_out, amps_dev, s),
+                       fbi_pca_clean_f64(p, cube, mean_dev, modes_dev, nmodes, cube_out, amps_dev, s));
 }
 
 // ---- foreground maps / cube, radiometer noise (the steps after the density-field path) -------------------------

@@ -932,4 +932,125 @@ __global__ __launch_bounds__(256) void k_sky_noise_cube(const T* __restrict__ un
     for (int u = 0; u < 4; ++u) out[4 * q + u] = (T)((double)g[u] * sigma[z0 + u]);
 }
 
+// ---- PCA foreground cleaning (fastbox/filters.py:93-183): channel means, frequency-frequency covariance,
+// projection onto the leading modes.  The cube is T[pixel = (x, y)][channel] with the channel contiguous. ----------
+
+// partial[block][channel] = sum over the block's pixels (fp64); k_bin_finish-style fixed-order finish below
+template <typename T>
+__global__ __launch_bounds__(256) void k_channel_sums(const T* __restrict__ cube, double* __restrict__ partial,
+                                                      long long npix, int N) {
+    const long long per = (npix + gridDim.x - 1) / gridDim.x;
+    const long long p0 = (long long)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        long long p = p0;
+        for (; p + 3 < p1; p += 4) {
+            a0 += (double)cube[p * N + c]; a1 += (double)cube[(p + 1) * N + c];
+            a2 += (double)cube[(p + 2) * N + c]; a3 += (double)cube[(p + 3) * N + c];
+        }
+        for (; p < p1; ++p) a0 += (double)cube[p * N + c];
+        partial[(size_t)blockIdx.x * N + c] = (a0 + a1) + (a2 + a3);
+    }
+}
+static __global__ void k_channel_means(const double* __restrict__ partial, int nblocks, int N, double inv_npix,
+                                       double* __restrict__ mean) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * N + c];
+    mean[c] = s * inv_npix;
+}
+
+// Covariance partials on the fp64 matrix cores.  cov[a][b] = sum_p x[p][a] x[p][b], x = cube - mean: a rank-4
+// update per v_mfma_f64_16x16x4_f64 (A: 16 channels x 4 pixels, lane l holds x[p0 + (l >> 4)][a0 + (l & 15)]; B the
+// same for the b block; D: col = l & 15, row = (l >> 4) + 4 reg).  One wave owns a (16 MA)^2 block of the matrix
+// (MA^2 accumulators of 8 VGPRs) for one slice of the pixels; operands come straight from global memory (each wave's
+// loads are 64-byte runs along the channel axis, shared through L1/L2 by the waves of the same pixel slice).  Only
+// blocks with bi <= bj are launched; partial[slice][a][b] are summed in slice order afterwards (deterministic).
+typedef double fb_d4 __attribute__((ext_vector_type(4)));
+template <typename T, int MA>
+__global__ __launch_bounds__(64) void k_channel_cov(const T* __restrict__ cube, const double* __restrict__ mean,
+                                                    double* __restrict__ partial, long long npix, int N, int nbs) {
+    // blockIdx.x -> (bi <= bj) pair, blockIdx.y -> pixel slice
+    int bi = 0, rem = blockIdx.x;
+    while (rem >= nbs - bi) { rem -= nbs - bi; ++bi; }
+    const int bj = bi + rem;
+    const int lane = threadIdx.x, lc = lane & 15, lk = lane >> 4;
+    const int a0 = bi * 16 * MA, b0 = bj * 16 * MA;
+    const long long per = ((npix + gridDim.y - 1) / gridDim.y + 3) & ~3LL;
+    const long long p0 = (long long)blockIdx.y * per, p1 = p0 + per < npix ? p0 + per : npix;
+    double ma[MA], mb[MA];
+#pragma unroll
+    for (int i = 0; i < MA; ++i) { ma[i] = mean[a0 + 16 * i + lc]; mb[i] = mean[b0 + 16 * i + lc]; }
+    fb_d4 acc[MA][MA];
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+        for (int j = 0; j < MA; ++j) acc[i][j] = fb_d4{0.0, 0.0, 0.0, 0.0};
+    for (long long p = p0; p < p1; p += 4) {
+        const long long row = p + lk;
+        const bool ok = row < p1;                       // npix % 4 == 0 for every grid this library plans
+        const T* src = cube + (ok ? row : p) * N;
+        double av[MA], bv[MA];
+#pragma unroll
+        for (int i = 0; i < MA; ++i) {
+            av[i] = ok ? (double)src[a0 + 16 * i + lc] - ma[i] : 0.0;
+            bv[i] = ok ? (double)src[b0 + 16 * i + lc] - mb[i] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < MA; ++i)
+#pragma unroll
+            for (int j = 0; j < MA; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    double* dst = partial + (size_t)blockIdx.y * N * N;
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+        for (int j = 0; j < MA; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst[(size_t)(a0 + 16 * i + lk + 4 * r) * N + b0 + 16 * j + lc] = acc[i][j][r];
+}
+// cov[a][b] = cov[b][a] = sum over slices / (npix - 1) for a's block <= b's block (np.cov's divisor)
+static __global__ void k_cov_finish(const double* __restrict__ partial, int nslices, int N, int bs, double inv,
+                                    double* __restrict__ cov) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, a = blockIdx.y;
+    if (b >= N || a / bs > b / bs) return;
+    double s = 0.0;
+    for (int q = 0; q < nslices; ++q) s += partial[((size_t)q * N + a) * N + b];
+    s *= inv;
+    cov[(size_t)a * N + b] = s;
+    if (a / bs != b / bs) cov[(size_t)b * N + a] = s;
+}
+
+// cleaned[p][c] = x[p][c] - sum_m U[c][m] amp_m(p), amp_m(p) = sum_c U[c][m] x[p][c], x = cube - mean
+// (filters.py:170-176).  One wave per pixel; U = [N][nm] fp64 (L1/L2 resident); optional amps_out[nm][npix].
+template <typename T, int CPL>          // CPL = channels per lane = max(1, N / 64)
+__global__ __launch_bounds__(256) void k_pca_clean(const T* __restrict__ cube, const double* __restrict__ mean,
+                                                   const double* __restrict__ U, int nm, T* __restrict__ out,
+                                                   double* __restrict__ amps_out, long long npix, int N) {
+    const int lane = threadIdx.x & 63;
+    const long long p = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= npix) return;
+    double x[CPL], rec[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int c = lane + 64 * q;
+        x[q] = c < N ? (double)cube[p * N + c] - mean[c] : 0.0;
+        rec[q] = 0.0;
+    }
+    for (int m = 0; m < nm; ++m) {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { const int c = lane + 64 * q; if (c < N) a += U[(size_t)c * nm + m] * x[q]; }
+        a = wave_sum(a);
+        if (amps_out && lane == 0) amps_out[(size_t)m * npix + p] = a;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { const int c = lane + 64 * q; if (c < N) rec[q] += U[(size_t)c * nm + m] * a; }
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) { const int c = lane + 64 * q; if (c < N) out[p * N + c] = (T)(x[q] - rec[q]); }
+}
+
 }  // namespace fb

@@ -35,6 +35,8 @@ struct fb_plan {
     void* amp_shell = nullptr;   // [nshell] plan precision, index n^2 = i^2+j^2+l^2 (cubic only)
     int64_t nshell = 0;
     const void* amp_dense = nullptr;  // caller-owned [N][N][NZP]
+    void* pca_work = nullptr;    // channel-sum / covariance partials (grown on demand)
+    size_t pca_work_cap = 0;
     double* kperp_tab = nullptr; // [N][N] 2 pi sqrt((m_x/L_x)^2 + (m_y/L_y)^2), box.py:374
     void* amp_sym = nullptr;     // [N/2+1][N/2+1][NZP] plan precision: amp_shell spread over (|m_x|, |m_y|, k_z)
 
@@ -67,7 +69,7 @@ struct fb_plan {
 
 // kernel classes reported by fb_profile_stop (keep in sync with FB_PROF_* in fastbox_hip.h)
 enum { FBK_FFT_STRIDED = 0, FBK_FFT_CONTIG, FBK_COLOUR, FBK_BIN, FBK_FILTER, FBK_VELPOT, FBK_REALOP, FBK_RSD,
-       FBK_LAYOUT, FBK_FFT_GEN, FBK_FFT_BIN, FBK_NCAT };
+       FBK_LAYOUT, FBK_FFT_GEN, FBK_FFT_BIN, FBK_PCA, FBK_NCAT };
 
 // RAII: records an event pair around one launch while profiling is on
 struct FbProfScope {
@@ -104,6 +106,10 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_colour_device_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* out, hipStream_t s); \
     int fbi_power_filtered_##sfx(fb_plan* p, const void* real_in, void* filtered_half, int kind, const double* prm, \
                                  const void* table, double* results, hipStream_t s); \
+    int fbi_channel_means_##sfx(fb_plan* p, const void* cube, double* mean_dev, hipStream_t s); \
+    int fbi_channel_cov_##sfx(fb_plan* p, const void* cube, const double* mean_dev, double* cov_dev, hipStream_t s); \
+    int fbi_pca_clean_##sfx(fb_plan* p, const void* cube, const double* mean_dev, const double* U_dev, int nm, \
+                            void* out, double* amps_dev, hipStream_t s); \
     int fbi_real_axpby_##sfx(fb_plan* p, const void* x, const void* y, void* out, double a, double b, double c, \
                              int mul, hipStream_t s); \
     int fbi_fft2d_c2c_##sfx(fb_plan* p, void* data, int sign, double scale, hipStream_t s); \

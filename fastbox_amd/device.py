@@ -529,7 +529,7 @@ class Engine(object):
 
     # -- profiling ------------------------------------------------------------------------
     PROF_NAMES = ("fft_strided", "fft_contig", "colour", "bin", "filter", "velpot", "realop", "rsd", "layout",
-                  "fft_gen", "fft_bin")
+                  "fft_gen", "fft_bin", "pca")
 
     def profile_start(self, only=None):
         """Bracket kernel launches with HIP events; `only` = iterable of class names to restrict to."""

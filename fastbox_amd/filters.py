@@ -1,0 +1,83 @@
+"""
+Foreground cleaning of a data cube on the device: the step between "add foregrounds and noise" and
+"estimate the power spectrum" in the reference's end-to-end flow (examples/example_endtoend.py:105-111).
+Same function names, arguments and return values as fastbox/filters.py (:35-56, :93-183).
+
+The cube never leaves HBM: channel means, the frequency-frequency covariance (N^2 pixels x N x N
+channels, on the fp64 matrix cores) and the projection run in libfastbox_hip.  Only the N x N covariance
+comes to the host, for the eigen-decomposition (an N x N symmetric problem: numpy.linalg.eigh), and the
+nmodes leading eigenvectors go back.  The cleaned cube depends only on the span of those modes, so it
+equals the reference's (which uses the unsymmetric solver numpy.linalg.eig); individual eigenvectors and
+mode amplitudes may differ from the reference's by a sign.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .device import REAL, DeviceArray
+
+
+def _as_cube(field, box=None):
+    if isinstance(field, DeviceArray):
+        if field.kind != REAL:
+            raise TypeError("expected a real-space cube")
+        return field
+    if box is None:
+        raise TypeError("a host array needs `box=` (the CosmoBox whose engine holds the cube)")
+    return box._as_real(field)
+
+
+def _channel_means(eng, cube):
+    mean = eng._alloc_bytes(eng.N * 8)
+    _lib.call("fb_channel_means", eng._plan, cube.ptr, mean.ptr, eng.stream)
+    return mean
+
+
+def mean_spectrum_filter(field, box=None):
+    """Subtract the mean of every frequency channel (filters.py:35-56)."""
+    cube = _as_cube(field, box)
+    eng = cube.engine
+    mean = _channel_means(eng, cube)
+    out = eng.empty(REAL)
+    _lib.call("fb_pca_clean", eng._plan, cube.ptr, mean.ptr, None, 0, out.ptr, None, eng.stream)
+    return out
+
+
+def pca_filter(field, nmodes, fit_powerlaw=False, return_filter=False, box=None):
+    """Remove the `nmodes` leading eigenmodes of the empirical frequency-frequency covariance
+    (filters.py:93-183).  Returns the cleaned cube (DeviceArray) and, if `return_filter`, the mode matrix
+    U_fg (Nfreq, nmodes) and the amplitudes fg_amps (nmodes, Npix) as host arrays."""
+    cube = _as_cube(field, box)
+    eng = cube.engine
+    N = eng.N
+    mean = _channel_means(eng, cube)
+    if fit_powerlaw:
+        # filters.py:146-154: replace the mean spectrum by a power-law fit of it (N numbers: host)
+        from scipy.optimize import curve_fit
+        h = np.empty(N)
+        _lib.call("fb_memcpy_d2h", h.ctypes.data_as(ctypes.c_void_p), mean.ptr, h.nbytes, eng.stream)
+        freqs = np.linspace(1., 10., N)
+
+        def fn(nu, amp, beta):
+            return amp * (nu / nu[0]) ** beta
+        pfit, _ = curve_fit(fn, freqs, h, p0=[h[0], -2.7])
+        h = np.ascontiguousarray(fn(freqs, pfit[0], pfit[1]))
+        _lib.call("fb_memcpy_h2d", mean.ptr, h.ctypes.data_as(ctypes.c_void_p), h.nbytes, eng.stream)
+    cov_dev = eng._alloc_bytes(N * N * 8)
+    _lib.call("fb_channel_covariance", eng._plan, cube.ptr, mean.ptr, cov_dev.ptr, eng.stream)
+    cov = np.empty((N, N))
+    _lib.call("fb_memcpy_d2h", cov.ctypes.data_as(ctypes.c_void_p), cov_dev.ptr, cov.nbytes, eng.stream)
+    # filters.py:161-169: eigenvectors by decreasing eigenvalue, keep nmodes
+    w, v = np.linalg.eigh(cov)
+    U_fg = np.ascontiguousarray(v[:, ::-1][:, :nmodes])
+    U_dev = eng.upload_raw(U_fg)
+    out = eng.empty(REAL)
+    amps_dev = eng._alloc_bytes(max(1, nmodes) * N * N * 8) if return_filter else None
+    _lib.call("fb_pca_clean", eng._plan, cube.ptr, mean.ptr, U_dev.ptr, int(nmodes), out.ptr,
+              amps_dev.ptr if amps_dev is not None else None, eng.stream)
+    if not return_filter:
+        return out
+    fg_amps = np.empty((nmodes, N * N))
+    _lib.call("fb_memcpy_d2h", fg_amps.ctypes.data_as(ctypes.c_void_p), amps_dev.ptr, fg_amps.nbytes, eng.stream)
+    return out, U_fg, fg_amps

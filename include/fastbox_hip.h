@@ -184,6 +184,17 @@ int fb_profile_stop(fb_plan* plan, void* stream, double* ms, int64_t* launches, 
 int fb_real_axpby(fb_plan* plan, const void* x, const void* y, void* out, double a, double b, double c, void* stream);
 int fb_real_multiply(fb_plan* plan, const void* x, const void* y, void* out, void* stream);
 
+/* ---- PCA foreground cleaning of a data cube T[N][N][N] (frequency = last axis), fastbox/filters.py:93-183 ----
+ * mean_dev[N]: per-channel mean over the N^2 pixels (:142), fp64 on the DEVICE.                                   */
+int fb_channel_means(fb_plan* plan, const void* cube, double* mean_dev, void* stream);
+/* cov_dev[N][N] = np.cov of the mean-subtracted channels (:157-158; divisor N^2 - 1), fp64 on the DEVICE, formed on
+ * the fp64 matrix cores (v_mfma_f64_16x16x4_f64) with a fixed summation order.  The caller takes its leading
+ * eigenvectors (:161-169; an N x N problem) and hands them back as modes_dev[N][nmodes] (fp64, DEVICE).            */
+int fb_channel_covariance(fb_plan* plan, const void* cube, const double* mean_dev, double* cov_dev, void* stream);
+/* cube_out = cube - (U (U^T x) + mean), x = cube - mean (:172-176); amps_dev[nmodes][N^2] = U^T x (:172) or NULL   */
+int fb_pca_clean(fb_plan* plan, const void* cube, const double* mean_dev, const double* modes_dev, int nmodes,
+                 void* cube_out, double* amps_dev, void* stream);
+
 /* ---- the steps after the density-field path: foregrounds (fastbox/foregrounds.py:48-175) and radiometer
  * noise (fastbox/noise.py:25-75).  2-D maps are T[N][N] over (x, y); cubes T[N][N][N], frequency axis last. ---- */
 /* realise_foreground_amp (:99-107): map_out = Re ifft2((re + i im) amp2d) + monopole.  amp2d = sqrt(C_ell) per

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 
 from oracle import standin                                              # noqa: E402
-from oracle.ref_loader import load_reference_box, load_reference_module   # noqa: E402
+from oracle.ref_loader import load_reference_box, load_reference_module, load_reference_filters   # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 CASES = [("sky_n16", 16, (3e3, 3e3, 3e3), 0.8, 5), ("sky_n32", 32, (4e3, 4e3, 2e3), 0.5, 9)]
@@ -47,6 +47,17 @@ def main():
         np.random.seed(seed + 3)
         out["noise_cube"] = noise_mod.NoiseModel(box).realise_radiometer_noise(Tinst=18., tp=2., fov=1., Ndish=64)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        # filters.py on a data cube = signal-like field + foregrounds + noise (example_endtoend.py:105-111)
+        filt = load_reference_filters()
+        rs = np.random.RandomState(seed + 4)
+        data = 0.1 * (1. + 0.3 * rs.normal(size=(N, N, N))) + out["fg_cube"] + out["noise_cube"]
+        pca = dict(N=N, seed=seed, data=data, mean_sub=filt.mean_spectrum_filter(data))
+        for nm in (2, 4):
+            cleaned, U, amps = filt.pca_filter(data, nmodes=nm, return_filter=True)
+            pca["cleaned%d" % nm] = cleaned
+            pca["U%d" % nm] = U
+            pca["amps%d" % nm] = amps
+        np.savez_compressed(os.path.join(OUT, name.replace("sky", "pca") + ".npz"), **pca)
         print("wrote", name, {k: getattr(v, "shape", v) for k, v in out.items() if k in ("fg_map", "fg_cube", "noise_cube")})
 
 

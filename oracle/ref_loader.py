@@ -93,3 +93,38 @@ def load_reference_module(relpath, name):
         else:
             sys.modules["pyccl"] = had
     return mod
+
+
+def load_reference_filters():
+    """fastbox/filters.py does `from .foregrounds import ...`: give it a stand-in parent package whose __path__ is
+    the reference directory (fastbox/__init__.py itself is NOT executed: it imports modules that are absent here)."""
+    if not os.path.exists("/root/reference/fastbox/filters.py"):
+        raise RuntimeError("reference sources are not present on this machine")
+    sys.dont_write_bytecode = True
+    import importlib
+    import warnings
+    import matplotlib
+    matplotlib.use("Agg")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    from fastbox_amd import cosmology as cosmo_mod
+    shim = types.ModuleType("pyccl")
+    for nm in ("Cosmology", "nonlin_matter_power", "linear_matter_power", "h_over_h0", "growth_rate",
+               "growth_factor", "comoving_angular_distance"):
+        setattr(shim, nm, getattr(cosmo_mod, nm))
+    had = sys.modules.get("pyccl")
+    sys.modules["pyccl"] = shim
+    pkg = types.ModuleType("_fastbox_reference_pkg")
+    pkg.__path__ = ["/root/reference/fastbox"]
+    sys.modules["_fastbox_reference_pkg"] = pkg
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mod = importlib.import_module("_fastbox_reference_pkg.filters")
+    finally:
+        if had is None:
+            sys.modules.pop("pyccl", None)
+        else:
+            sys.modules["pyccl"] = had
+    return mod

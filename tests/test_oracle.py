@@ -141,3 +141,20 @@ def test_sky_oracle_reproduces_reference_vectors(golden_dir, name):
     for ax in (0, 1):
         mine = sum(w[j] * np.roll(mine, rad - j, axis=ax) for j in range(2 * rad + 1))
     assert np.max(np.abs(mine - scipy.ndimage.gaussian_filter(x, 4. / pix, mode="wrap"))) < 1e-13
+
+
+@pytest.mark.parametrize("name", ["pca_n16", "pca_n32"])
+def test_pca_oracle_reproduces_reference_vectors(golden_dir, name):
+    from oracle import pca_oracle as po
+    g = _load(golden_dir, name)
+    data = g["data"]
+    assert _same(po.mean_spectrum_filter(data), g["mean_sub"])
+    for nm in (2, 4):
+        cleaned, U, amps = po.pca_filter(data, nm, return_filter=True)
+        assert _same(cleaned, g["cleaned%d" % nm]) and _same(U, g["U%d" % nm]) and _same(amps, g["amps%d" % nm])
+        # what the device path is held to: the cleaned cube only depends on the span of the leading modes
+        _, x, cov = po.channel_covariance(data)
+        w, v = np.linalg.eigh(cov)
+        Uh = v[:, ::-1][:, :nm]
+        alt = data - (Uh @ (Uh.T @ x) + np.mean(data.reshape(-1, data.shape[-1]), axis=0)[:, None]).T.reshape(data.shape)
+        assert np.max(np.abs(alt - cleaned)) < 1e-9 * np.max(np.abs(data))

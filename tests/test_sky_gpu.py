@@ -99,3 +99,56 @@ def test_cube_arithmetic_stays_on_the_device(precision, tol):
     cube = a
     cube += b                                                   # __iadd__ falls back to a new device cube
     assert isinstance(cube, DeviceArray) and np.max(np.abs(np.asarray(cube) - (ha + hb))) <= tol * np.max(np.abs(ha + hb))
+
+
+@pytest.mark.parametrize("name", ["pca_n16", "pca_n32"])
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-9), ("f32", 3e-6)])
+def test_pca_filter_matches_reference_vectors(golden_dir, name, precision, tol):
+    """fastbox_amd.filters against vectors from the reference's filters.py: the cleaned cube (which depends only on
+    the span of the modes), the projector U U^T, the amplitudes up to a sign per mode."""
+    from fastbox_amd import CosmoBox, filters
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    N, data = int(g["N"]), g["data"]
+    box = CosmoBox(cosmo=standin.DEFAULT_COSMO, box_scale=1e3, nsamp=N, realise_now=False, precision=precision)
+    cube = box.engine.upload(data, "real")
+    scale = np.max(np.abs(data))
+    ms = np.asarray(filters.mean_spectrum_filter(cube))
+    assert np.max(np.abs(ms - g["mean_sub"])) < tol * scale
+    for nm in (2, 4):
+        cleaned, U, amps = filters.pca_filter(cube, nm, return_filter=True)
+        assert np.max(np.abs(np.asarray(cleaned) - g["cleaned%d" % nm])) < tol * scale
+        Ur = g["U%d" % nm].real
+        # fp32 storage of the cube perturbs the noise-dominated modes (nearly degenerate eigenvalues) at the 1e-4
+        # level; the cleaned cube above is insensitive to that
+        assert U.shape == Ur.shape and np.max(np.abs(U @ U.T - Ur @ Ur.T)) < (1e-3 if precision == "f32" else 1e-9)
+        sgn = np.sign(np.sum(U * Ur, axis=0))
+        ref_amps = g["amps%d" % nm].real
+        assert np.max(np.abs(amps * sgn[:, None] - ref_amps)) < (2e-3 if precision == "f32" else 1e-9) * np.max(np.abs(ref_amps))
+        only = filters.pca_filter(data, nm, box=box)                       # host array in, no filter returned
+        assert np.max(np.abs(np.asarray(only) - g["cleaned%d" % nm])) < tol * scale
+
+
+def test_channel_covariance_on_the_matrix_cores_full_size():
+    """N = 256 (the 64 x 64 block shape, several block pairs and pixel slices): the MFMA covariance against numpy
+    on the same fp32 cube, and the cleaning identities (cleaned channels have zero mean and no component along U)."""
+    from fastbox_amd import CosmoBox, filters, _lib
+    import ctypes
+    N = 256
+    box = CosmoBox(cosmo=standin.DEFAULT_COSMO, box_scale=1e3, nsamp=N, realise_now=False, precision="f32", rng="device", seed=3)
+    rs = np.random.RandomState(0)
+    spec = 50. * (np.linspace(1., 2., N)[None, :] ** -2.7) * (1. + 0.3 * rs.normal(size=(N * N, 1)))
+    data = (spec + 0.05 * rs.normal(size=(N * N, N))).astype(np.float32).reshape(N, N, N)
+    cube = box.engine.upload(data, "real")
+    eng = box.engine
+    mean = filters._channel_means(eng, cube)
+    cov_dev = eng._alloc_bytes(N * N * 8)
+    _lib.call("fb_channel_covariance", eng._plan, cube.ptr, mean.ptr, cov_dev.ptr, eng.stream)
+    cov = np.empty((N, N))
+    _lib.call("fb_memcpy_d2h", cov.ctypes.data_as(ctypes.c_void_p), cov_dev.ptr, cov.nbytes, eng.stream)
+    want = np.cov(data.reshape(-1, N).astype(np.float64).T)
+    assert np.max(np.abs(cov - want)) < 1e-11 * np.max(np.abs(want))
+    assert np.array_equal(cov, cov.T)
+    cleaned, U, amps = filters.pca_filter(cube, 3, return_filter=True)
+    c = np.asarray(cleaned).reshape(-1, N)
+    assert np.max(np.abs(c.mean(axis=0))) < 1e-6 and np.max(np.abs(c @ U)) < 2e-4
+    assert np.std(c) < 0.06                                                # the smooth foreground is gone
