@@ -952,13 +952,23 @@ __global__ __launch_bounds__(256) void k_channel_sums(const T* __restrict__ cube
         partial[(size_t)blockIdx.x * N + c] = (a0 + a1) + (a2 + a3);
     }
 }
+// blockDim = (64 channels, 4 groups of workgroup partials); fixed order: group sums, then the four groups
 static __global__ void k_channel_means(const double* __restrict__ partial, int nblocks, int N, double inv_npix,
                                        double* __restrict__ mean) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+    __shared__ double sh[4][64];
+    const int c = blockIdx.x * 64 + threadIdx.x, grp = threadIdx.y;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * N + c];
-    mean[c] = s * inv_npix;
+    if (c < N) {
+        const int per = (nblocks + 3) / 4, b1 = (grp + 1) * per < nblocks ? (grp + 1) * per : nblocks;
+        double s0 = 0.0, s1 = 0.0;
+        int b = grp * per;
+        for (; b + 1 < b1; b += 2) { s0 += partial[(size_t)b * N + c]; s1 += partial[(size_t)(b + 1) * N + c]; }
+        if (b < b1) s0 += partial[(size_t)b * N + c];
+        s = s0 + s1;
+    }
+    sh[grp][threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && c < N) mean[c] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x])) * inv_npix;
 }
 
 // Covariance partials on the fp64 matrix cores.  cov[a][b] = sum_p x[p][a] x[p][b], x = cube - mean: a rank-4
@@ -987,21 +997,44 @@ __global__ __launch_bounds__(64) void k_channel_cov(const T* __restrict__ cube, 
     for (int i = 0; i < MA; ++i)
 #pragma unroll
         for (int j = 0; j < MA; ++j) acc[i][j] = fb_d4{0.0, 0.0, 0.0, 0.0};
-    for (long long p = p0; p < p1; p += 4) {
-        const long long row = p + lk;
-        const bool ok = row < p1;                       // npix % 4 == 0 for every grid this library plans
-        const T* src = cube + (ok ? row : p) * N;
-        double av[MA], bv[MA];
+    // Software pipeline: the raw operands of the NEXT group of KU rank-4 updates are fetched before the matrix
+    // instructions of the current group are issued, so that memory latency hides behind 16 MA^2/4 ... KU of them.
+    constexpr int KU = 4;
+    T fa[2][KU][MA], fb_[2][KU][MA];
+    auto fetch = [&](int buf, long long p) {
 #pragma unroll
-        for (int i = 0; i < MA; ++i) {
-            av[i] = ok ? (double)src[a0 + 16 * i + lc] - ma[i] : 0.0;
-            bv[i] = ok ? (double)src[b0 + 16 * i + lc] - mb[i] : 0.0;
+        for (int u = 0; u < KU; ++u) {
+            const long long row = p + 4 * u + lk;
+            const T* src = cube + (row < p1 ? row : p0) * N;       // past the slice: any valid row, masked below
+#pragma unroll
+            for (int i = 0; i < MA; ++i) { fa[buf][u][i] = src[a0 + 16 * i + lc]; fb_[buf][u][i] = src[b0 + 16 * i + lc]; }
         }
+    };
+    auto update = [&](int buf, long long p) {
 #pragma unroll
-        for (int i = 0; i < MA; ++i)
+        for (int u = 0; u < KU; ++u) {
+            const bool ok = p + 4 * u + lk < p1;
+            double av[MA], bv[MA];
 #pragma unroll
-            for (int j = 0; j < MA; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MA; ++i) {
+                av[i] = ok ? (double)fa[buf][u][i] - ma[i] : 0.0;
+                bv[i] = ok ? (double)fb_[buf][u][i] - mb[i] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < MA; ++i)
+#pragma unroll
+                for (int j = 0; j < MA; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    fetch(0, p0);
+    for (long long p = p0; p < p1; p += 8 * KU) {
+        fetch(1, p + 4 * KU);
+        update(0, p);
+        if (p + 4 * KU < p1) {
+            fetch(0, p + 8 * KU);
+            update(1, p + 4 * KU);
+        }
     }
     double* dst = partial + (size_t)blockIdx.y * N * N;
 #pragma unroll

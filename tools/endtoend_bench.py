@@ -1,11 +1,11 @@
-"""The reference's end-to-end flow (examples/example_endtoend.py steps 1-3 and the high-pass of step 5) on one GPU,
+"""The reference's end-to-end flow (examples/example_endtoend.py steps 1-4 and the high-pass of step 5) on one GPU,
 everything resident in HBM: log-normal tracer field in redshift space -> brightness temperature cube -> + Gaussian
-foregrounds -> + radiometer noise -> k_par high-pass -> P(k).  The tracer bias / mean temperature (tracers.py) are
+foregrounds -> + radiometer noise -> PCA cleaning -> k_par high-pass -> P(k).  The tracer bias / mean temperature (tracers.py) are
 plain numbers here.  python tools/endtoend_bench.py [N]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from fastbox_amd import CosmoBox, default_cosmo, ForegroundModel, NoiseModel, BeamHighpass
+from fastbox_amd import CosmoBox, default_cosmo, ForegroundModel, NoiseModel, BeamHighpass, filters
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 box = CosmoBox(cosmo=default_cosmo, box_scale=(4e3, 4e3, 4e3), nsamp=N, redshift=0.8, realise_now=False,
@@ -26,6 +26,7 @@ def flow():
     alpha = fg.realise_spectral_index(mean_spec_idx=2.07, std_spec_idx=0.0002, smoothing_scale=15.)
     data_cube = signal_cube + fg.construct_cube(fg_map, alpha, freq_ref=130.)
     data_cube = data_cube + noise_model.realise_radiometer_noise(Tinst=18., tp=2., fov=1., Ndish=64)   # (3)
+    data_cube = filters.pca_filter(data_cube, nmodes=4)                           # (4) PCA foreground cleaning
     cleaned = box.apply_transfer_fn(box.to_k(data_cube), highpass)                # (5) k_par high-pass
     return box.binned_power_spectrum(delta_x=cleaned.real, nbins=20, wait=False)
 
