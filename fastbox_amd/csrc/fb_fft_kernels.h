@@ -52,6 +52,14 @@ template <typename T> struct StridedArgs {
     int drop_io;             // tuning aid: do all the arithmetic but no global loads/stores
     int stagger;             // first-generation workgroups [num_cu, 2 num_cu) sleep this many x64 cycles
     int num_cu;
+    // Exchange-buffer addressing of the slab-decomposed transform (all zero = the plain layout on both sides).
+    // A line of the blocked side is cut into 2^blk_shift ... pieces: point k lives at
+    // (k / B) * blk_stride + (k % B) * stride with B = (N / elements-per-thread) << blk_shift points per piece,
+    // i.e. the [rank][x][k_y in rank][k_z] buffer that goes into / comes out of the all-to-all, so that the y pass
+    // itself does the pack / unpack.  out_outer_stride = 0 means "as outer_stride".
+    long long out_outer_stride;
+    long long blk_stride;
+    int blk_in, blk_out, blk_shift;
 };
 
 // operands of the fused modes (x pass of a half spectrum: line index = k_x,
@@ -132,6 +140,12 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     const long long tbase = (long long)t0 * a.stride;
     const unsigned loff = (unsigned)(((long long)(t - t0) * a.stride + c) * (long long)sizeof(cx<T>));
     const long long estep = (long long)TPL * a.stride;
+    // offset of a thread's e-th point (e is a compile-time constant after unrolling, the rest is wave-uniform)
+    auto eoff = [&](int e, int blocked) -> long long {
+        return blocked ? (long long)(e >> a.blk_shift) * a.blk_stride + (long long)(e & ((1 << a.blk_shift) - 1)) * estep
+                       : (long long)e * estep;
+    };
+    const long long out_outer = a.out_outer_stride ? a.out_outer_stride : a.outer_stride;
 
     cx<T> v[E];
     [[maybe_unused]] cx<T> vn[E];
@@ -143,7 +157,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         const cx<T>* src = a.in + ((long long)(tile_id / a.ntx) * a.outer_stride + bx0 * TZ + tbase);
         const unsigned voff = bx0 * TZ + c < a.ncols ? loff : FB_BUF_OOB;
 #pragma unroll
-        for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + e * estep), voff, src);
+        for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + eoff(e, a.blk_in)), voff, src);
         if constexpr (!smode_bins(MODE)) {
             // E stores that the range check discards: they make the memory-op queue at loop entry
             // look like the queue at the back edge (E loads, then E stores), so that the compiler's
@@ -249,7 +263,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             const cx<T>* src = a.in + ubase + tbase;
             const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = buf_load(make_rsrc(src + e * estep), voff, src);
+            for (int e = 0; e < E; ++e) v[e] = buf_load(make_rsrc(src + eoff(e, a.blk_in)), voff, src);
         } else {
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = vn[e];
@@ -262,7 +276,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             const cx<T>* src = a.in + ((long long)(nxt / a.ntx) * a.outer_stride + nbx * TZ + tbase);
             const unsigned voff = (nxt < a.ntiles && nbx * TZ + c < a.ncols) ? loff : FB_BUF_OOB;
 #pragma unroll
-            for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + e * estep), voff, src);
+            for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + eoff(e, a.blk_in)), voff, src);
         }
 #ifdef FB_STAMPS
         FB_STAMP(1);
@@ -314,10 +328,10 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             }
         }
         if constexpr (!smode_bins(MODE) || MODE == SMODE_BINF) {
-            cx<T>* dst = a.out + ubase + tbase;
+            cx<T>* dst = a.out + ((long long)by * out_outer + bx * TZ) + tbase;
             const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
 #pragma unroll
-            for (int e = 0; e < E; ++e) buf_store(make_rsrc(dst + e * estep), voff, cscale(v[e], a.scale));
+            for (int e = 0; e < E; ++e) buf_store(make_rsrc(dst + eoff(e, a.blk_out)), voff, cscale(v[e], a.scale));
         }
         if constexpr (smode_bins(MODE)) {
             // Re-stage p = |X|^2 through LDS so that each lane bins E consecutive elements of

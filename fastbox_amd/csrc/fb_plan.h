@@ -106,6 +106,10 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_colour_device_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* out, hipStream_t s); \
     int fbi_power_filtered_##sfx(fb_plan* p, const void* real_in, void* filtered_half, int kind, const double* prm, \
                                  const void* table, double* results, hipStream_t s); \
+    int fbi_slab_forward_packed_##sfx(fb_plan* p, const void* real_local, void* half_local, void* xbuf, int nxl, \
+                                      int nparts, int pre_exp, double* expsum, hipStream_t s); \
+    int fbi_slab_inverse_packed_##sfx(fb_plan* p, const void* xbuf, void* half_local, void* real_local, int nxl, \
+                                      int nparts, double scale, hipStream_t s); \
     int fbi_channel_means_##sfx(fb_plan* p, const void* cube, double* mean_dev, hipStream_t s); \
     int fbi_channel_cov_##sfx(fb_plan* p, const void* cube, const double* mean_dev, double* cov_dev, hipStream_t s); \
     int fbi_pca_clean_##sfx(fb_plan* p, const void* cube, const double* mean_dev, const double* U_dev, int nm, \

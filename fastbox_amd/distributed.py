@@ -11,9 +11,11 @@ xGMI on the GPUs, "gloo" on CPUs for tests):
                kslab = complex[N][N/P][pitch]                      (k_z fastest, Hermitian half)
 
   realise_density : generator fused into the x pass of the kslab  -> all-to-all (the kslab's N/P-plane
-                    blocks are already contiguous: no pack)       -> unpack -> y pass + z c2r
-  P(k)            : z r2c + y pass on the x-slab -> pack -> all-to-all -> the receive buffer IS the
-                    kslab -> x pass with fused shell binning -> all-reduce of 2*nbins+1 doubles
+                    blocks are already contiguous: no pack)       -> y pass (reads the receive buffer
+                    directly: no unpack kernel) + z c2r
+  P(k)            : z r2c + y pass on the x-slab (writes the send buffer directly: no pack kernel)
+                    -> all-to-all -> the receive buffer IS the kslab -> x pass with fused shell
+                    binning -> all-reduce of 2*nbins+1 doubles
 
 Each ordered pair of ranks exchanges (N/P)(N/P)(pitch) complex values; with P = 8 all 7 xGMI links of
 a GPU carry one peer each.  The device noise depends on global mode indices only, so the field is
@@ -90,6 +92,16 @@ class HipSlabOps(object):
         self._call("fb_slab_forward_local", real.data_ptr(), half_local.data_ptr(), self.P, 1 if pre_exp else 0,
                    expsum.data_ptr() if pre_exp else None, self._stream())
 
+    fused_exchange = True          # the y pass writes / reads the all-to-all buffer itself (no pack / unpack kernels)
+
+    def forward_packed(self, real, half_local, send, pre_exp, expsum):
+        self._call("fb_slab_forward_packed", real.data_ptr(), half_local.data_ptr(), send.data_ptr(), self.P,
+                   1 if pre_exp else 0, expsum.data_ptr() if pre_exp else None, self._stream())
+
+    def inverse_packed(self, recv, half_local, real):
+        self._call("fb_slab_inverse_packed", recv.data_ptr(), half_local.data_ptr(), real.data_ptr(), self.P,
+                   self._stream())
+
     def pack(self, half_local, send):
         self._call("fb_slab_pack", half_local.data_ptr(), send.data_ptr(), self.P, self._stream())
 
@@ -142,15 +154,17 @@ class SlabBox(object):
         return self.world > 1 and t.is_cuda and self._dist.get_backend(self.group) == "gloo"
 
     def _exchange(self, send, recv):
+        """All-to-all of equal blocks; returns the buffer that holds the result (`send` itself for one rank)."""
         if self.world == 1:
-            recv.copy_(send)
-        elif self._host_staged(send):
+            return send
+        if self._host_staged(send):
             h_in = send.detach().cpu().view(-1)
             h_out = h_in.new_empty(h_in.shape)
             self._dist.all_to_all_single(h_out, h_in, group=self.group)
             recv.view(-1).copy_(h_out)
         else:
             self._dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+        return recv
 
     def _all_reduce(self, t):
         if self.world == 1:
@@ -169,17 +183,19 @@ class SlabBox(object):
         return self._kslab
 
     def _gen_finish(self, recv):
-        self.ops.unpack(recv, self._half)
         real = self.ops.new_real()
-        self.ops.inverse_local(self._half, real)
+        if getattr(self.ops, "fused_exchange", False):
+            self.ops.inverse_packed(recv, self._half, real)
+        else:
+            self.ops.unpack(recv, self._half)
+            self.ops.inverse_local(self._half, real)
         self.delta_x = real
         return real
 
     def realise_density(self):
         """This rank's x-slab of delta_x (kept in ``self.delta_x``)."""
         send = self._gen_local()
-        self._exchange(send, self._xbuf)
-        return self._gen_finish(self._xbuf)
+        return self._gen_finish(self._exchange(send, self._xbuf))
 
     # -- binned_power_spectrum (box.py:696-768) ----------------------------------------------
     def _pk_setup(self, nbins, kbins):
@@ -192,8 +208,11 @@ class SlabBox(object):
 
     def _pk_local(self, real, lognormal, nb):
         self._res = self.ops.new_results(2 * nb + 1)
-        self.ops.forward_local(real, self._half, lognormal, self._res[2 * nb:])
-        self.ops.pack(self._half, self._xbuf)
+        if getattr(self.ops, "fused_exchange", False):
+            self.ops.forward_packed(real, self._half, self._xbuf, lognormal, self._res[2 * nb:])
+        else:
+            self.ops.forward_local(real, self._half, lognormal, self._res[2 * nb:])
+            self.ops.pack(self._half, self._xbuf)
         return self._xbuf
 
     def _pk_finish(self, kslab, nb):
@@ -209,8 +228,7 @@ class SlabBox(object):
         if lognormal and not bins[0] > 0.:
             raise ValueError("the fused log-normal P(k) needs kbins[0] > 0")
         send = self._pk_local(real, lognormal, nb)
-        self._exchange(send, self._kslab)
-        res = self._pk_finish(self._kslab, nb)
+        res = self._pk_finish(self._exchange(send, self._kslab), nb)
         self._all_reduce(res)                                     # 2*nbins+1 doubles
         h = res.detach().cpu().numpy()
         s1, s2, esum = h[0:2 * nb:2].copy(), h[1:2 * nb:2].copy(), h[2 * nb]

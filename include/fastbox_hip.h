@@ -232,6 +232,12 @@ int64_t fb_slab_kspace_bytes(const fb_plan* plan, int nparts);   /* kslab = all-
 int fb_slab_forward_local(fb_plan* plan, const void* real_local, void* half_local, int nparts, int pre_exp,
                           double* expsum_dev, void* stream);
 int fb_slab_inverse_local(fb_plan* plan, void* half_local, void* real_local, int nparts, void* stream);
+/* the same two with fb_slab_pack / fb_slab_unpack folded into the y pass (it writes / reads the exchange buffer
+ * directly); needs nparts to divide the points each thread holds of a y line: 1, 2, 4, 8 ranks (16 at N = 2048) */
+int fb_slab_forward_packed(fb_plan* plan, const void* real_local, void* half_local, void* sendbuf, int nparts,
+                           int pre_exp, double* expsum_dev, void* stream);
+int fb_slab_inverse_packed(fb_plan* plan, const void* recvbuf, void* half_local, void* real_local, int nparts,
+                           void* stream);
 int fb_slab_pack(fb_plan* plan, const void* half_local, void* sendbuf, int nparts, void* stream);
 int fb_slab_unpack(fb_plan* plan, const void* recvbuf, void* half_local, int nparts, void* stream);
 int fb_slab_x_pass(fb_plan* plan, void* kslab, int nparts, int direction, void* stream);
