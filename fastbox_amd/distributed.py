@@ -148,6 +148,20 @@ class SlabBox(object):
         self._half = self.ops.new_half_local()
         self.delta_x = None
 
+    def _fused(self, call):
+        """Run the exchange-buffer-addressing form of a y pass if the backend has it and the rank count allows it
+        (it must divide the points a thread holds of a line); False = use pack / unpack instead."""
+        if not getattr(self.ops, "fused_exchange", False):
+            return False
+        try:
+            call()
+            return True
+        except Exception as e:                      # FastBoxError(FB_ERR_UNSUPPORTED): remember and fall back
+            if getattr(e, "code", None) != -3:
+                raise
+            self.ops.fused_exchange = False
+            return False
+
     # -- the single data-path collective --------------------------------------------------
     def _host_staged(self, t):
         """gloo has no device all-to-all: stage through the host (tests on a single GPU only)."""
@@ -184,9 +198,7 @@ class SlabBox(object):
 
     def _gen_finish(self, recv):
         real = self.ops.new_real()
-        if getattr(self.ops, "fused_exchange", False):
-            self.ops.inverse_packed(recv, self._half, real)
-        else:
+        if not self._fused(lambda: self.ops.inverse_packed(recv, self._half, real)):
             self.ops.unpack(recv, self._half)
             self.ops.inverse_local(self._half, real)
         self.delta_x = real
@@ -208,9 +220,8 @@ class SlabBox(object):
 
     def _pk_local(self, real, lognormal, nb):
         self._res = self.ops.new_results(2 * nb + 1)
-        if getattr(self.ops, "fused_exchange", False):
-            self.ops.forward_packed(real, self._half, self._xbuf, lognormal, self._res[2 * nb:])
-        else:
+        if not self._fused(lambda: self.ops.forward_packed(real, self._half, self._xbuf, lognormal,
+                                                             self._res[2 * nb:])):
             self.ops.forward_local(real, self._half, lognormal, self._res[2 * nb:])
             self.ops.pack(self._half, self._xbuf)
         return self._xbuf

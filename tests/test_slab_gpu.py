@@ -8,12 +8,14 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("f64", 1e-11)])
-@pytest.mark.parametrize("P", [1, 2, 4])
-def test_virtual_ranks_match_single_gpu(P, precision, tol):
+@pytest.mark.parametrize("P,N", [(1, 64), (2, 64), (4, 64), (8, 64), (8, 128), (16, 64)])
+def test_virtual_ranks_match_single_gpu(P, N, precision, tol):
+    """P = 1..8: the y pass addresses the exchange buffer itself (8 points per thread of a line, cut into
+    8/P-point pieces); P = 16 does not divide 8: falls back to the pack / unpack kernels."""
     from fastbox_amd import CosmoBox, default_cosmo
     from fastbox_amd.distributed import HipSlabOps, SlabBox, run_virtual
     from fastbox_amd import hostgeom
-    N, L, seed = 64, 1e3, 77
+    L, seed = 1e3, 77
     ref = CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, precision=precision,
                    rng="device", seed=seed)
     want_dx = np.asarray(ref.realise_density())
@@ -26,6 +28,7 @@ def test_virtual_ranks_match_single_gpu(P, precision, tol):
     reals = run_virtual(boxes, lambda b: b._gen_local(), lambda b, recv: b._gen_finish(recv))
     dx = np.concatenate([r.double().cpu().numpy() for r in reals], axis=0)
     assert np.max(np.abs(dx - want_dx)) < tol * np.std(want_dx)
+    assert all(b.ops.fused_exchange == (P <= 8) for b in boxes)
 
     for lognormal, want in ((False, want_pk), (True, want_ln)):
         nb = 20
