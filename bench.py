@@ -202,8 +202,7 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
                   device=local_rank)
 
     def step():
-        box.realise_density()
-        return box.binned_power_spectrum(nbins=args.nbins, lognormal=True)
+        return box.realise_and_power(nbins=args.nbins, lognormal=True)
 
     def fence():
         torch.cuda.synchronize()

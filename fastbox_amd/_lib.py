@@ -75,6 +75,7 @@ SIGNATURES = {
     "fb_slab_inverse_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fb_slab_forward_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fb_slab_inverse_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "fb_slab_turnaround": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fb_slab_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fb_slab_unpack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fb_slab_x_pass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -428,6 +428,17 @@ int fb_slab_inverse_packed(fb_plan* p, const void* recvbuf, void* half_local, vo
     return FB_DISPATCH(p, fbi_slab_inverse_packed_f32(p, recvbuf, half_local, real_local, nxl, nparts, scale, s),
                        fbi_slab_inverse_packed_f64(p, recvbuf, half_local, real_local, nxl, nparts, scale, s));
 }
+int fb_slab_turnaround(fb_plan* p, const void* recvbuf, void* half_local, void* real_local, void* sendbuf, int nparts,
+                       int pre_exp, double* expsum_dev, void* stream) {
+    FB_SLAB_CHECK(p, nparts);
+    FB_REQUIRE(recvbuf && half_local && real_local && sendbuf && half_local != recvbuf && half_local != sendbuf,
+               "bad buffers");
+    hipStream_t s = (hipStream_t)stream;
+    const int nxl = p->N / nparts;
+    const double scale = 1.0 / ((double)p->N * p->N * p->N);
+    return FB_DISPATCH(p, fbi_slab_turnaround_f32(p, recvbuf, half_local, real_local, sendbuf, nxl, nparts, scale, pre_exp, expsum_dev, s),
+                       fbi_slab_turnaround_f64(p, recvbuf, half_local, real_local, sendbuf, nxl, nparts, scale, pre_exp, expsum_dev, s));
+}
 int fb_slab_pack(fb_plan* p, const void* half_local, void* sendbuf, int nparts, void* stream) {
     FB_SLAB_CHECK(p, nparts);
     FB_REQUIRE(half_local && sendbuf && half_local != sendbuf, "bad buffers");

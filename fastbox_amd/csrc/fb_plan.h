@@ -110,6 +110,8 @@ int fb_hip_check(hipError_t e, const char* what);
                                       int nparts, int pre_exp, double* expsum, hipStream_t s); \
     int fbi_slab_inverse_packed_##sfx(fb_plan* p, const void* xbuf, void* half_local, void* real_local, int nxl, \
                                       int nparts, double scale, hipStream_t s); \
+    int fbi_slab_turnaround_##sfx(fb_plan* p, const void* recvbuf, void* half_local, void* real_local, void* sendbuf, \
+                                  int nxl, int nparts, double scale, int pre_exp, double* expsum, hipStream_t s); \
     int fbi_channel_means_##sfx(fb_plan* p, const void* cube, double* mean_dev, hipStream_t s); \
     int fbi_channel_cov_##sfx(fb_plan* p, const void* cube, const double* mean_dev, double* cov_dev, hipStream_t s); \
     int fbi_pca_clean_##sfx(fb_plan* p, const void* cube, const double* mean_dev, const double* U_dev, int nm, \

@@ -102,6 +102,10 @@ class HipSlabOps(object):
         self._call("fb_slab_inverse_packed", recv.data_ptr(), half_local.data_ptr(), real.data_ptr(), self.P,
                    self._stream())
 
+    def turnaround(self, recv, half_local, real, send, pre_exp, expsum):
+        self._call("fb_slab_turnaround", recv.data_ptr(), half_local.data_ptr(), real.data_ptr(), send.data_ptr(),
+                   self.P, 1 if pre_exp else 0, expsum.data_ptr() if pre_exp else None, self._stream())
+
     def pack(self, half_local, send):
         self._call("fb_slab_pack", half_local.data_ptr(), send.data_ptr(), self.P, self._stream())
 
@@ -147,6 +151,7 @@ class SlabBox(object):
         self._xbuf = self.ops.new_kslab()          # same byte count as [P][N/P][N/P][pitch]
         self._half = self.ops.new_half_local()
         self.delta_x = None
+        self._bin_cache, self._bins_set = {}, None
 
     def _fused(self, call):
         """Run the exchange-buffer-addressing form of a y pass if the backend has it and the rank count allows it
@@ -211,12 +216,21 @@ class SlabBox(object):
 
     # -- binned_power_spectrum (box.py:696-768) ----------------------------------------------
     def _pk_setup(self, nbins, kbins):
-        bins, kc = hostgeom.bin_edges(self.g, nbins, kbins)
-        thr, amb = hostgeom.shell_thresholds(self.N, self.g["L"][0], bins)
-        if thr is None:
-            raise ValueError("these bin edges cannot be expressed as shell thresholds")
-        self.ops.set_bins(bins, thr, amb)
-        return bins, kc
+        key = ("n", int(nbins)) if kbins is None else ("k", np.asarray(kbins, dtype=np.float64).tobytes())
+        hit = self._bin_cache.get(key)
+        if hit is None:                       # np.digitize over every shell: once per bin set, not per realisation
+            bins, kc = hostgeom.bin_edges(self.g, nbins, kbins)
+            thr, amb = hostgeom.shell_thresholds(self.N, self.g["L"][0], bins)
+            if thr is None:
+                raise ValueError("these bin edges cannot be expressed as shell thresholds")
+            if len(self._bin_cache) > 16:
+                self._bin_cache.clear()
+            hit = self._bin_cache[key] = (bins, kc, thr, amb)
+        bins, kc, thr, amb = hit
+        if self._bins_set != key:
+            self.ops.set_bins(bins, thr, amb)
+            self._bins_set = key
+        return bins, kc.copy()
 
     def _pk_local(self, real, lognormal, nb):
         self._res = self.ops.new_results(2 * nb + 1)
@@ -230,6 +244,36 @@ class SlabBox(object):
         self.ops.x_bin(kslab, self._res)
         return self._res
 
+    def realise_and_power(self, nbins=20, kbins=None, lognormal=False):
+        """``realise_density()`` followed by ``binned_power_spectrum(lognormal=...)`` of the new field, as the
+        Monte-Carlo loop does, with the z passes of the two fused: the real slab is written once, not read back.
+        Returns (kc, pk, stddev); ``self.delta_x`` holds the slab."""
+        bins, kc = self._pk_setup(nbins, kbins)
+        nb = bins.size
+        if lognormal and not bins[0] > 0.:
+            raise ValueError("the fused log-normal P(k) needs kbins[0] > 0")
+        recv = self._exchange(self._gen_local(), self._xbuf)
+        self._res = self.ops.new_results(2 * nb + 1)
+        real = self.ops.new_real()
+        send = self._kslab if recv is self._xbuf else self._xbuf           # the buffer the exchange did not return
+        if self._fused(lambda: self.ops.turnaround(recv, self._half, real, send, lognormal, self._res[2 * nb:])):
+            self.delta_x = real
+        else:
+            real = self._gen_finish(recv)
+            send = self._pk_local(real, lognormal, nb)
+        other = self._kslab if send is self._xbuf else self._xbuf
+        res = self._pk_finish(self._exchange(send, other), nb)
+        return self._finish_power(res, kc, nb, lognormal)
+
+    def _finish_power(self, res, kc, nb, lognormal):
+        self._all_reduce(res)                                     # 2*nbins+1 doubles
+        h = res.detach().cpu().numpy()
+        s1, s2, esum = h[0:2 * nb:2].copy(), h[1:2 * nb:2].copy(), h[2 * nb]
+        if lognormal:
+            mean = esum / float(self.N) ** 3
+            s1, s2 = s1 / mean ** 2, s2 / mean ** 4
+        return (kc,) + hostgeom.finish_bins(self.ops.bin_counts(), s1, s2, self.boxfactor)
+
     def binned_power_spectrum(self, delta_x=None, nbins=20, kbins=None, lognormal=False):
         """P(k) of the distributed field (of its log-normal transform if ``lognormal``); every rank
         returns the full (kc, pk, stddev) triple."""
@@ -240,13 +284,7 @@ class SlabBox(object):
             raise ValueError("the fused log-normal P(k) needs kbins[0] > 0")
         send = self._pk_local(real, lognormal, nb)
         res = self._pk_finish(self._exchange(send, self._kslab), nb)
-        self._all_reduce(res)                                     # 2*nbins+1 doubles
-        h = res.detach().cpu().numpy()
-        s1, s2, esum = h[0:2 * nb:2].copy(), h[1:2 * nb:2].copy(), h[2 * nb]
-        if lognormal:
-            mean = esum / float(self.N) ** 3
-            s1, s2 = s1 / mean ** 2, s2 / mean ** 4
-        return (kc,) + hostgeom.finish_bins(self.ops.bin_counts(), s1, s2, self.boxfactor)
+        return self._finish_power(res, kc, nb, lognormal)
 
 
 def run_virtual(boxes, fn_local, fn_finish):
@@ -254,12 +292,11 @@ def run_virtual(boxes, fn_local, fn_finish):
     slab kernels on a single GPU): phase 1 on every rank, the all-to-all by block copies, phase 2."""
     P = len(boxes)
     sends = [fn_local(b) for b in boxes]
-    outs = []
-    for r, b in enumerate(boxes):
-        n = sends[0].shape[0] // P
+    recvs = []
+    for r, b in enumerate(boxes):                  # the whole exchange first: phase 2 may reuse the send buffers
         recv = b._xbuf if sends[r] is not b._xbuf else b._kslab
         flat = recv.view(P, -1)
         for q in range(P):
             flat[q].copy_(sends[q].view(P, -1)[r])
-        outs.append(fn_finish(b, recv))
-    return outs
+        recvs.append(recv)
+    return [fn_finish(b, recv) for b, recv in zip(boxes, recvs)]

@@ -238,6 +238,11 @@ int fb_slab_forward_packed(fb_plan* plan, const void* real_local, void* half_loc
                            int pre_exp, double* expsum_dev, void* stream);
 int fb_slab_inverse_packed(fb_plan* plan, const void* recvbuf, void* half_local, void* real_local, int nparts,
                            void* stream);
+/* fb_slab_inverse_packed followed by fb_slab_forward_packed of the field just made, with the two z passes as one:
+ * real_local (this rank's x-slab of delta_x) is written once and never read back.  recvbuf and sendbuf may be
+ * the same buffer only if it is not half_local (the y passes are out of place).                                   */
+int fb_slab_turnaround(fb_plan* plan, const void* recvbuf, void* half_local, void* real_local, void* sendbuf,
+                       int nparts, int pre_exp, double* expsum_dev, void* stream);
 int fb_slab_pack(fb_plan* plan, const void* half_local, void* sendbuf, int nparts, void* stream);
 int fb_slab_unpack(fb_plan* plan, const void* recvbuf, void* half_local, int nparts, void* stream);
 int fb_slab_x_pass(fb_plan* plan, void* kslab, int nparts, int direction, void* stream);

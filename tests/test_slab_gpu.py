@@ -50,6 +50,43 @@ def test_virtual_ranks_match_single_gpu(P, N, precision, tol):
         assert np.all(np.abs(err[m] - want[2][m]) <= ptol * (np.abs(want[2][m]) + np.abs(want[1][m])))
 
 
+@pytest.mark.parametrize("P", [1, 2, 8])
+def test_turnaround_fuses_the_z_passes(P):
+    """fb_slab_turnaround (inverse y from the receive buffer, one z pass writing delta_x and the forward z spectrum
+    of exp(delta_x), forward y into the send buffer) against the single-GPU field and log-normal P(k)."""
+    from fastbox_amd import CosmoBox, default_cosmo, hostgeom
+    from fastbox_amd.distributed import HipSlabOps, SlabBox, run_virtual
+    N, L, seed, nb = 64, 1e3, 5, 20
+    ref = CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, precision="f32", rng="device", seed=seed)
+    want_dx = np.asarray(ref.realise_density())
+    want = ref.binned_power_spectrum(delta_x=ref.lognormal(ref.delta_x), nbins=nb)
+    boxes = [SlabBox(default_cosmo, box_scale=L, nsamp=N, precision="f32", seed=seed, rank=r, world=P,
+                     ops_factory=lambda g, PP, rr: HipSlabOps(g, PP, rr, precision="f32", device=0)) for r in range(P)]
+    for b in boxes:
+        b._pk_setup(nb, None)
+
+    def turn(b, recv):
+        b._res = b.ops.new_results(2 * nb + 1)
+        b.delta_x = b.ops.new_real()
+        b._send2 = b._kslab if recv is b._xbuf else b._xbuf
+        b.ops.turnaround(recv, b._half, b.delta_x, b._send2, True, b._res[2 * nb:])
+        return b._send2
+    run_virtual(boxes, lambda b: b._gen_local(), turn)
+    dx = np.concatenate([b.delta_x.double().cpu().numpy() for b in boxes], axis=0)
+    assert np.max(np.abs(dx - want_dx)) < 2e-5 * np.std(want_dx)
+    res = run_virtual(boxes, lambda b: b._send2, lambda b, kslab: b._pk_finish(kslab, nb).clone())
+    h = sum(r.cpu().numpy() for r in res)
+    mean = h[2 * nb] / float(N) ** 3
+    pk, err = hostgeom.finish_bins(boxes[0].ops.bin_counts(), h[0:2 * nb:2] / mean ** 2, h[1:2 * nb:2] / mean ** 4,
+                                   boxes[0].boxfactor)
+    m = ~np.isnan(want[1])
+    assert np.array_equal(np.isnan(pk), np.isnan(want[1])) and np.allclose(pk[m], want[1][m], rtol=1e-5, atol=0)
+    if P == 1:                                   # the public entry point, one rank
+        kc, pk1, err1 = boxes[0].realise_and_power(nbins=nb, lognormal=True)
+        ref2 = ref.binned_power_spectrum(delta_x=ref.lognormal(ref.realise_density()), nbins=nb)
+        assert np.allclose(pk1[m], ref2[1][m], rtol=1e-5, atol=0)
+
+
 def _gloo_worker(rank, world, port, out_dir, N, L, seed):
     import os
     import sys
@@ -67,10 +104,9 @@ def _gloo_worker(rank, world, port, out_dir, N, L, seed):
         from fastbox_amd.distributed import SlabBox
         box = SlabBox(default_cosmo, box_scale=L, nsamp=N, precision="f32", seed=seed, device=0)
         mark("SlabBox built")
-        dx = box.realise_density().double().cpu().numpy()
-        mark("density realised")
-        pk = box.binned_power_spectrum(nbins=20, lognormal=True)
-        mark("power spectrum done")
+        pk = box.realise_and_power(nbins=20, lognormal=True)
+        dx = box.delta_x.double().cpu().numpy()
+        mark("density realised, power spectrum done")
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), dx=dx, pk=np.array(pk))
     finally:
         dist.destroy_process_group()
