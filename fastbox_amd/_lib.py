@@ -61,6 +61,9 @@ SIGNATURES = {
     "fb_bin_counts": (c_int, [c_void_p, P_double]),
     "fb_real_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_void_p]),
     "fb_real_multiply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fb_real_to_complex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fb_fft_transverse": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "fb_mask_transverse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_channel_means": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_channel_covariance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_pca_clean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

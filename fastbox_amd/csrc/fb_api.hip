@@ -327,6 +327,25 @@ int fb_real_multiply(fb_plan* p, const void* x, const void* y, void* out, void* 
     return FB_DISPATCH(p, fbi_real_axpby_f32(p, x, y, out, 0, 0, 0, 1, s), fbi_real_axpby_f64(p, x, y, out, 0, 0, 0, 1, s));
 }
 
+// ---- transverse (per-channel 2-D) transforms and masks (fastbox/filters.py:58-90) ---------------------------------
+int fb_fft_transverse(fb_plan* p, void* full_cube, int direction, void* stream) {
+    FB_REQUIRE(p && full_cube, "null pointer");
+    FB_REQUIRE(direction == 1 || direction == -1, "direction must be -1 (fftn) or +1 (ifftn)");
+    hipStream_t s = (hipStream_t)stream;
+    const double scale = direction > 0 ? 1.0 / ((double)p->N * p->N) : 1.0;
+    return FB_DISPATCH(p, fbi_fft_axes01_f32(p, full_cube, direction, scale, s), fbi_fft_axes01_f64(p, full_cube, direction, scale, s));
+}
+int fb_real_to_complex(fb_plan* p, const void* real_cube, void* full_cube, void* stream) {
+    FB_REQUIRE(p && real_cube && full_cube, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_real_to_complex_f32(p, real_cube, full_cube, s), fbi_real_to_complex_f64(p, real_cube, full_cube, s));
+}
+int fb_mask_transverse(fb_plan* p, void* full_cube, const void* mask2d, void* stream) {
+    FB_REQUIRE(p && full_cube && mask2d, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_mask_xy_f32(p, full_cube, mask2d, s), fbi_mask_xy_f64(p, full_cube, mask2d, s));
+}
+
 // ---- PCA foreground cleaning (fastbox/filters.py:93-183) -----------------------------------------------------
 int fb_channel_means(fb_plan* p, const void* cube, double* mean_dev, void* stream) {
     FB_REQUIRE(p && cube && mean_dev, "null pointer");

@@ -932,6 +932,23 @@ __global__ __launch_bounds__(256) void k_sky_noise_cube(const T* __restrict__ un
     for (int u = 0; u < 4; ++u) out[4 * q + u] = (T)((double)g[u] * sigma[z0 + u]);
 }
 
+// real cube -> complex cube (imaginary part 0); complex cube *= mask2d[k_x][k_y] (filters.py:79-89)
+template <typename T>
+__global__ void k_real_to_complex(const T* __restrict__ in, cx<T>* __restrict__ out, long long n) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x)
+        out[q] = cx<T>{in[q], (T)0};
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_mask_xy(cx<T>* __restrict__ cube, const T* __restrict__ mask2d, int N) {
+    const long long row = blockIdx.x;                     // (k_x, k_y)
+    const T m = mask2d[row];
+    if (m == (T)1) return;                                // block-uniform: untouched rows cost nothing
+    for (int z = threadIdx.x; z < N; z += blockDim.x) {
+        cx<T> v = cube[row * N + z];
+        cube[row * N + z] = cx<T>{v.x * m, v.y * m};
+    }
+}
+
 // ---- PCA foreground cleaning (fastbox/filters.py:93-183): channel means, frequency-frequency covariance,
 // projection onto the leading modes.  The cube is T[pixel = (x, y)][channel] with the channel contiguous. ----------
 

@@ -15,7 +15,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .device import REAL, DeviceArray
+from .device import FULL, REAL, DeviceArray
 
 
 def _few_blas_threads():
@@ -97,3 +97,27 @@ def pca_filter(field, nmodes, fit_powerlaw=False, return_filter=False, box=None)
     fg_amps = np.empty((nmodes, N * N))
     _lib.call("fb_memcpy_d2h", fg_amps.ctypes.data_as(ctypes.c_void_p), amps_dev.ptr, fg_amps.nbytes, eng.stream)
     return out, U_fg, fg_amps
+
+
+def angular_bandpass_filter(field, kmin, kmax, d=1., box=None):
+    """Top-hat band-pass in |k_perp| applied to every frequency channel (filters.py:58-90).  Returns the complex
+    cube ifftn(fftn(field, axes=[0, 1]) * mask, axes=[0, 1]) as a device array, like the reference's result."""
+    if isinstance(field, DeviceArray) and field.kind == FULL:
+        eng = field.engine
+        cube = eng.clone(field)
+    else:
+        real = _as_cube(field, box)
+        eng = real.engine
+        cube = eng.empty(FULL)
+        _lib.call("fb_real_to_complex", eng._plan, real.ptr, cube.ptr, eng.stream)
+    N = eng.N
+    kx = np.fft.fftfreq(N, d=d)                               # :83-86, N^2 numbers on the host
+    kx, ky = np.meshgrid(kx, kx)
+    k = np.sqrt(kx ** 2. + ky ** 2.)
+    mask = np.logical_and(k >= kmin, k < kmax).astype(eng.rdtype)
+    mask_dev = eng.upload_raw(np.ascontiguousarray(mask))
+    _lib.call("fb_fft_transverse", eng._plan, cube.ptr, -1, eng.stream)
+    _lib.call("fb_mask_transverse", eng._plan, cube.ptr, mask_dev.ptr, eng.stream)
+    _lib.call("fb_fft_transverse", eng._plan, cube.ptr, +1, eng.stream)
+    cube.invalidate()
+    return cube

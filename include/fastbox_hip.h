@@ -184,6 +184,14 @@ int fb_profile_stop(fb_plan* plan, void* stream, double* ms, int64_t* launches, 
 int fb_real_axpby(fb_plan* plan, const void* x, const void* y, void* out, double a, double b, double c, void* stream);
 int fb_real_multiply(fb_plan* plan, const void* x, const void* y, void* out, void* stream);
 
+/* ---- per-channel 2-D operations on a complex cube complex<T>[N][N][N] (frequency = last axis), as
+ * filters.angular_bandpass_filter (fastbox/filters.py:58-90) needs them ----
+ * fb_fft_transverse: np.fft.fftn(cube, axes=[0,1]) (direction -1) / np.fft.ifftn(cube, axes=[0,1]) (+1), in place.
+ * fb_mask_transverse: cube[kx, ky, :] *= mask2d[kx][ky] (T[N][N] on the device; :89).                             */
+int fb_real_to_complex(fb_plan* plan, const void* real_cube, void* full_cube, void* stream);
+int fb_fft_transverse(fb_plan* plan, void* full_cube, int direction, void* stream);
+int fb_mask_transverse(fb_plan* plan, void* full_cube, const void* mask2d, void* stream);
+
 /* ---- PCA foreground cleaning of a data cube T[N][N][N] (frequency = last axis), fastbox/filters.py:93-183 ----
  * mean_dev[N]: per-channel mean over the N^2 pixels (:142), fp64 on the DEVICE.                                   */
 int fb_channel_means(fb_plan* plan, const void* cube, double* mean_dev, void* stream);

@@ -57,6 +57,8 @@ def main():
             pca["cleaned%d" % nm] = cleaned
             pca["U%d" % nm] = U
             pca["amps%d" % nm] = amps
+        pca["bandpass"] = filt.angular_bandpass_filter(data, 0.08, 0.3, d=1.)
+        pca["bandpass_d2"] = filt.angular_bandpass_filter(data, 0.0, 0.11, d=2.)
         np.savez_compressed(os.path.join(OUT, name.replace("sky", "pca") + ".npz"), **pca)
         print("wrote", name, {k: getattr(v, "shape", v) for k, v in out.items() if k in ("fg_map", "fg_cube", "noise_cube")})
 

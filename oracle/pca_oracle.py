@@ -38,3 +38,13 @@ def pca_filter(field, nmodes, return_filter=False):
     if return_filter:
         return cleaned_field, U_fg, fg_amps
     return cleaned_field
+
+
+def angular_bandpass_filter(field, kmin, kmax, d=1.):
+    """filters.py:79-90: top-hat band-pass in |k_perp| of every frequency channel (2-D transforms over axes 0, 1)."""
+    field_k = np.fft.fftn(field, axes=[0, 1])
+    kx = np.fft.fftfreq(field.shape[0], d=d)
+    kx, ky = np.meshgrid(kx, kx)
+    k = np.sqrt(kx ** 2. + ky ** 2.)
+    field_k[~np.logical_and(k >= kmin, k < kmax)] *= 0.
+    return np.fft.ifftn(field_k, axes=[0, 1])

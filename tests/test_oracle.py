@@ -149,6 +149,8 @@ def test_pca_oracle_reproduces_reference_vectors(golden_dir, name):
     g = _load(golden_dir, name)
     data = g["data"]
     assert _same(po.mean_spectrum_filter(data), g["mean_sub"])
+    assert _same(po.angular_bandpass_filter(data, 0.08, 0.3, d=1.), g["bandpass"])
+    assert _same(po.angular_bandpass_filter(data, 0.0, 0.11, d=2.), g["bandpass_d2"])
     for nm in (2, 4):
         cleaned, U, amps = po.pca_filter(data, nm, return_filter=True)
         assert _same(cleaned, g["cleaned%d" % nm]) and _same(U, g["U%d" % nm]) and _same(amps, g["amps%d" % nm])

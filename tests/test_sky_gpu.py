@@ -152,3 +152,17 @@ def test_channel_covariance_on_the_matrix_cores_full_size():
     c = np.asarray(cleaned).reshape(-1, N)
     assert np.max(np.abs(c.mean(axis=0))) < 1e-6 and np.max(np.abs(c @ U)) < 2e-4
     assert np.std(c) < 0.06                                                # the smooth foreground is gone
+
+
+@pytest.mark.parametrize("name", ["pca_n16", "pca_n32"])
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-12), ("f32", 2e-6)])
+def test_angular_bandpass_filter_matches_reference_vectors(golden_dir, name, precision, tol):
+    from fastbox_amd import CosmoBox, filters
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    N, data = int(g["N"]), g["data"]
+    box = CosmoBox(cosmo=standin.DEFAULT_COSMO, box_scale=1e3, nsamp=N, realise_now=False, precision=precision)
+    scale = np.max(np.abs(data))
+    got = np.asarray(filters.angular_bandpass_filter(box.engine.upload(data, "real"), 0.08, 0.3, d=1.))
+    assert got.dtype == np.complex128 and np.max(np.abs(got - g["bandpass"])) < tol * scale
+    got2 = np.asarray(filters.angular_bandpass_filter(data, 0.0, 0.11, d=2., box=box))
+    assert np.max(np.abs(got2 - g["bandpass_d2"])) < tol * scale
