@@ -27,7 +27,9 @@ constexpr int strided_elems(int n) { return n >= FB_E16_FROM ? 16 : fb_min(8, n)
 // that a workgroup is at least one full wave.
 template <typename T> constexpr int tile_cols(int n) {
     return fb_max(fb_max(2, fb_min(128 / (2 * (int)sizeof(T)),
-                                   (n >= FB_E16_FROM ? 131072 : 65536) / (n * 2 * (int)sizeof(T)))),
+                                   // 16 points per thread: 128 KB tile (fp32), 64 KB for fp64 so that the tile, the
+                                   // fp64 twiddles (32 KB at 2048) and the binning rows stay within the 160 KB of a CU
+                                   (n >= FB_E16_FROM ? (sizeof(T) == 8 ? 65536 : 131072) : 65536) / (n * 2 * (int)sizeof(T)))),
                   64 / (n / strided_elems(n)));
 }
 
