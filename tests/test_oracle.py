@@ -160,3 +160,13 @@ def test_pca_oracle_reproduces_reference_vectors(golden_dir, name):
         Uh = v[:, ::-1][:, :nm]
         alt = data - (Uh @ (Uh.T @ x) + np.mean(data.reshape(-1, data.shape[-1]), axis=0)[:, None]).T.reshape(data.shape)
         assert np.max(np.abs(alt - cleaned)) < 1e-9 * np.max(np.abs(data))
+
+
+def test_host_side_helpers_of_the_sky_models_match_the_oracle():
+    """Host logic that needs no GPU: the smoothing kernel weights handed to fb_sky_gaussian_filter are scipy's."""
+    from fastbox_amd import sky
+    from oracle import sky_oracle as so
+    for sigma in (0.3, 1.0, 2.7, 11.5):
+        w, r = sky._gaussian_weights(sigma)
+        wo, ro = so.gaussian_weights(sigma)
+        assert r == ro and np.array_equal(w, wo) and abs(w.sum() - 1) < 1e-15
