@@ -576,6 +576,11 @@ class CosmoBox(object):
             out = (kc,) + _finish_bins(cnt, s1, s2, self.boxfactor)
             return out if wait else _Ready(out)
 
+        if delta_x is None and delta_k is None and thr is not None and self._delta_k is None \
+                and getattr(self, "delta_x", None) is not None:
+            # the stored realisation, whose fftn has not been asked for yet (box.py:736-739 would use
+            # self.delta_k = fftn(delta_x)): same numbers through the fused path below, no spectrum stored
+            delta_x = self.delta_x
         if delta_x is not None and thr is not None:
             # fused path (cubic boxes): r2c with the binning inside the last pass
             ln = isinstance(delta_x, LognormalField) and not delta_x.materialised and bins[0] > 0.
