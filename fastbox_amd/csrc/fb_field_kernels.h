@@ -373,7 +373,8 @@ void k_apply_filter(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, Filte
 // edge, four DPP wave sums, one lane adds into the wave's fp64 row.  Otherwise (several edges, a shell
 // within rounding of an edge, non-cubic box): bin per lane, one reduction per distinct bin (wave_flush).
 // Deterministic: fixed row -> wave assignment, fixed-order reductions.
-#define FB_BIN_GROUP 5
+#define FB_BIN_GROUP 5          // elements a lane holds per step: a half-spectrum row of N <= 512 is one step
+#define FB_BIN_MAXSPAN 8        // bins one row may touch on the fast path
 template <typename T>
 __global__ __launch_bounds__(64 * FB_BIN_WAVES)
 void k_bin_rows(const cx<T>* __restrict__ spec, double* __restrict__ partial, KGeom g, BinGeom bg, FilterSpec f,
@@ -397,68 +398,64 @@ void k_bin_rows(const cx<T>* __restrict__ spec, double* __restrict__ partial, KG
         const int mx = mode_of(i, N), my = mode_of(j, N);
         const int n2row = mx * mx + my * my;
         const double kperp = f.kind >= 0 ? kperp_exact(g, i, j) : 0.0;
-        const bool mono = !full_layout && N >= 128;
-        int bprev = 0;                                                 // bins below the row's first mode: found by the first step
+        // The row's n^2 runs from n2row (k_z = 0) to n2row + (N/2)^2, whichever the layout: the bins it can touch
+        // are blo..bhi, and a mode's bin is blo + the number of thresholds thr[blo..bhi-1] it has reached.
+        int blo = 0, bhi = 0, span = FB_BIN_MAXSPAN + 1;
+        int tv[FB_BIN_MAXSPAN];
+        if (bg.thr) {
+            blo = shell_bin(lthr, nb, n2row);
+            bhi = shell_bin(lthr, nb, n2row + (N >> 1) * (N >> 1));
+            span = bhi - blo;                                          // thresholds inside the row's range
+#pragma unroll
+            for (int u = 0; u < FB_BIN_MAXSPAN; ++u) tv[u] = (u < span && blo + u < nb) ? lthr[blo + u] : 0x7fffffff;
+        }
         for (int g0 = 0; g0 < nz; g0 += 64 * FB_BIN_GROUP) {
-            // all loads of the group first (a half-spectrum row of N <= 512 is one group): one request in
-            // flight per wave would leave the kernel latency-bound
+            // a lane takes FB_BIN_GROUP CONSECUTIVE k_z (its modes then differ little in |k|); all loads first
             cx<T> dv[FB_BIN_GROUP];
 #pragma unroll
             for (int c = 0; c < FB_BIN_GROUP; ++c) {
-                const int l = g0 + 64 * c + lane;
+                const int l = g0 + lane * FB_BIN_GROUP + c;
                 dv[c] = l < nz ? spec[base + l] : cx<T>{0, 0};
             }
+            double wp[FB_BIN_GROUP], wp2[FB_BIN_GROUP];   // fp64 sums: a bin of equal modes must come out with zero spread
+            int rel[FB_BIN_GROUP];
+            bool special = span > FB_BIN_MAXSPAN;                      // too many bins / no thresholds: per-mode path
 #pragma unroll
             for (int c = 0; c < FB_BIN_GROUP; ++c) {
-                const int l0 = g0 + 64 * c;
-                if (l0 >= nz) break;                                   // wave-uniform
-                const int l = l0 + lane;
+                const int l = g0 + lane * FB_BIN_GROUP + c;
                 const bool ok = l < nz;
                 cx<T> d = dv[c];
                 if (ok && f.kind >= 0) {
                     const T m = filter_value<T>(f, g, i, j, l, base + l, kperp);
                     d = cx<T>{nan_to_num(d.x * m), nan_to_num(d.y * m)};
                 }
-                const T p = d.x * d.x + d.y * d.y;
-                const T w = (full_layout || l == 0 || l == (N >> 1)) ? (T)1 : (T)2;
+                const double p = (double)(d.x * d.x + d.y * d.y);
+                const double w = !ok ? 0.0 : ((full_layout || l == 0 || l == (N >> 1)) ? 1.0 : 2.0);
+                wp[c] = w * p; wp2[c] = wp[c] * p;
                 const int ml = mode_of(l, N);
                 const int n2 = n2row + ml * ml;
-                bool done = false;
-                if (bg.thr) {
-                    int blo, bhi;
-                    if (mono) {
-                        // half-spectrum row, 64-aligned steps: n^2 grows with k_z, so the step's bounds are
-                        // its end points and the bins only move forward from the previous step's
-                        const int lend = l0 + 63 < nz ? l0 + 63 : nz - 1;
-                        const int wlo = n2row + l0 * l0, whi = n2row + lend * lend;
-                        blo = bprev;
-                        while (blo < nb && lthr[blo] <= wlo) ++blo;
-                        bhi = blo;
-                        while (bhi < nb && lthr[bhi] <= whi) ++bhi;
-                        bprev = blo;
-                    } else {
-                        const int wlo = wave_minmax<false>(ok ? n2 : 0x7fffffff), whi = wave_minmax<true>(ok ? n2 : -1);
-                        blo = shell_bin(lthr, nb, wlo); bhi = shell_bin(lthr, nb, whi);
-                    }
-                    bool mine = false;                 // a mode sitting ON a shell that needs the exact |k|
-                    for (int z = 0; z < bg.namb; ++z) mine |= ok && (bg.amb[z] == n2);
-                    if (bhi - blo <= 1 && !__any(mine)) {
-                        const int edge = (bhi > blo) ? lthr[blo] : 0x7fffffff;   // first n^2 of bin bhi
-                        const bool up = n2 >= edge;
-                        const T wp = ok ? w * p : (T)0, wp2 = wp * p;
-                        const T s1 = wave_sum(up ? (T)0 : wp), s2 = wave_sum(up ? (T)0 : wp2);
-                        if (bhi > blo) {
-                            const T u1 = wave_sum(up ? wp : (T)0), u2 = wave_sum(up ? wp2 : (T)0);
-                            if (lane == 0 && bhi < nb) { row_acc[2 * bhi] += (double)u1; row_acc[2 * bhi + 1] += (double)u2; }
-                        }
-                        if (lane == 0 && blo < nb) { row_acc[2 * blo] += (double)s1; row_acc[2 * blo + 1] += (double)s2; }
-                        done = true;
-                    }
+                int r = 0;
+#pragma unroll
+                for (int u = 0; u < FB_BIN_MAXSPAN; ++u) r += (n2 >= tv[u]) ? 1 : 0;
+                rel[c] = r;
+                for (int z = 0; z < bg.namb; ++z) special |= ok && (bg.amb[z] == n2);   // needs the exact |k|
+            }
+            if (!__any(special)) {
+                for (int u = 0; u <= span; ++u) {                       // wave-uniform trip count
+                    if (blo + u >= nb) break;
+                    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < FB_BIN_GROUP; ++c) { const bool in = rel[c] == u; s1 += in ? wp[c] : 0.0; s2 += in ? wp2[c] : 0.0; }
+                    s1 = wave_sum(s1); s2 = wave_sum(s2);
+                    if (lane == 0) { row_acc[2 * (blo + u)] += s1; row_acc[2 * (blo + u) + 1] += s2; }
                 }
-                if (!done) {
+            } else {
+#pragma unroll
+                for (int c = 0; c < FB_BIN_GROUP; ++c) {
+                    const int l = g0 + lane * FB_BIN_GROUP + c;
+                    const bool ok = l < nz;
                     const int b = ok ? bin_of_mode(bg, g, lbins, lthr, i, j, l) : nb;
-                    const double pd = (double)p, wd = (double)w;
-                    wave_flush(b, wd * pd, wd * pd * pd, ok && b < nb, row_acc);
+                    wave_flush(b, wp[c], wp2[c], ok && b < nb, row_acc);
                 }
             }
         }
@@ -467,7 +464,7 @@ void k_bin_rows(const cx<T>* __restrict__ spec, double* __restrict__ partial, KG
     for (int q = tid; q < 2 * nb; q += blockDim.x) {
         double s = 0.0;
         for (int w = 0; w < FB_BIN_WAVES; ++w) s += acc[(size_t)w * nb * 2 + q];
-        partial[(size_t)q * gridDim.x + blockIdx.x] = s;          // [value][workgroup]: see k_sum_columns
+        partial[(size_t)q * gridDim.x + blockIdx.x] = s;          // [value][workgroup]: see k_bin_finish
     }
 }
 
