@@ -400,14 +400,23 @@ void k_bin_rows(const cx<T>* __restrict__ spec, double* __restrict__ partial, KG
         const double kperp = f.kind >= 0 ? kperp_exact(g, i, j) : 0.0;
         // The row's n^2 runs from n2row (k_z = 0) to n2row + (N/2)^2, whichever the layout: the bins it can touch
         // are blo..bhi, and a mode's bin is blo + the number of thresholds thr[blo..bhi-1] it has reached.
-        int blo = 0, bhi = 0, span = FB_BIN_MAXSPAN + 1;
+        int blo = 0, bhi = 0, span;
         int tv[FB_BIN_MAXSPAN];
+        double ev[FB_BIN_MAXSPAN];
         if (bg.thr) {
             blo = shell_bin(lthr, nb, n2row);
             bhi = shell_bin(lthr, nb, n2row + (N >> 1) * (N >> 1));
             span = bhi - blo;                                          // thresholds inside the row's range
 #pragma unroll
             for (int u = 0; u < FB_BIN_MAXSPAN; ++u) tv[u] = (u < span && blo + u < nb) ? lthr[blo + u] : 0x7fffffff;
+        } else {
+            // any box shape: the same with the bin edges themselves and the exact fp64 |k| of every mode
+            // (|k| grows with |m_z| along the row, so its end points bound the bins)
+            blo = bin_exact(lbins, nb, kmag_exact(g, i, j, 0));
+            bhi = bin_exact(lbins, nb, kmag_exact(g, i, j, N >> 1));
+            span = bhi - blo;
+#pragma unroll
+            for (int u = 0; u < FB_BIN_MAXSPAN; ++u) ev[u] = (u < span && blo + u < nb) ? lbins[blo + u] : 1.0e300;
         }
         for (int g0 = 0; g0 < nz; g0 += 64 * FB_BIN_GROUP) {
             // a lane takes FB_BIN_GROUP CONSECUTIVE k_z (its modes then differ little in |k|); all loads first
@@ -435,10 +444,16 @@ void k_bin_rows(const cx<T>* __restrict__ spec, double* __restrict__ partial, KG
                 const int ml = mode_of(l, N);
                 const int n2 = n2row + ml * ml;
                 int r = 0;
+                if (bg.thr) {
 #pragma unroll
-                for (int u = 0; u < FB_BIN_MAXSPAN; ++u) r += (n2 >= tv[u]) ? 1 : 0;
+                    for (int u = 0; u < FB_BIN_MAXSPAN; ++u) r += (n2 >= tv[u]) ? 1 : 0;
+                    for (int z = 0; z < bg.namb; ++z) special |= ok && (bg.amb[z] == n2);   // needs the exact |k|
+                } else {
+                    const double k = kmag_exact(g, i, j, ok ? l : 0);
+#pragma unroll
+                    for (int u = 0; u < FB_BIN_MAXSPAN; ++u) r += (k >= ev[u]) ? 1 : 0;
+                }
                 rel[c] = r;
-                for (int z = 0; z < bg.namb; ++z) special |= ok && (bg.amb[z] == n2);   // needs the exact |k|
             }
             if (!__any(special)) {
                 for (int u = 0; u <= span; ++u) {                       // wave-uniform trip count
