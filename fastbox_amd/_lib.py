@@ -34,6 +34,7 @@ SIGNATURES = {
     "fb_fft_r2c": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fb_fft_c2r": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p]),
     "fb_set_amplitude_shells": (c_int, [c_void_p, P_double, c_i64]),
+    "fb_set_amplitude_sym": (c_int, [c_void_p, P_double, c_i64]),
     "fb_set_amplitude_dense": (c_int, [c_void_p, c_void_p]),
     "fb_colour_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_colour_device": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p]),

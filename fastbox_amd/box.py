@@ -331,12 +331,14 @@ class CosmoBox(object):
                 pk = np.nan_to_num(np.asarray(self._power(k, scale_factor, linear), dtype=np.float64))
                 self.engine.set_amplitude_shells(np.sqrt(pk * self.boxfactor))
             else:
-                nz = N // 2 + 1
+                # |k| depends on the mode numbers only through |m_x|, |m_y|, |m_z|: evaluate P(k) on the
+                # (N/2+1)^3 magnitudes (an eighth of the stored modes), in the reference's operation order
+                M = N // 2 + 1
                 a = self._axis2
-                s = (a[:N, None, None] + a[N:2 * N][None, :, None]) + a[2 * N:][None, None, :nz]
+                s = (a[:M, None, None] + a[N:N + M][None, :, None]) + a[2 * N:2 * N + M][None, None, :]
                 k = 2. * np.pi * np.sqrt(s)
                 pk = np.nan_to_num(np.asarray(self._power(k.flatten(), scale_factor, linear), dtype=np.float64))
-                self.engine.set_amplitude_dense(np.sqrt(pk.reshape(k.shape) * self.boxfactor))
+                self.engine.set_amplitude_sym(np.sqrt(pk.reshape(k.shape) * self.boxfactor))
         self._amp_key = key
 
     def realise_density(self, linear=False, redshift=None, inplace=True):

@@ -134,6 +134,10 @@ int fb_set_amplitude_shells(fb_plan* p, const double* amp, int64_t nshell) {
     p->amp_dense = nullptr;
     return FB_DISPATCH(p, fbi_set_amp_shells_f32(p, amp, nshell), fbi_set_amp_shells_f64(p, amp, nshell));
 }
+int fb_set_amplitude_sym(fb_plan* p, const double* amp, int64_t n) {
+    FB_REQUIRE(p && amp, "null pointer");
+    return FB_DISPATCH(p, fbi_set_amp_sym_f32(p, amp, n), fbi_set_amp_sym_f64(p, amp, n));
+}
 int fb_set_amplitude_dense(fb_plan* p, const void* amp_dev) {
     FB_REQUIRE(p && amp_dev, "null pointer");
     p->amp_dense = amp_dev;

@@ -79,6 +79,11 @@ __global__ void k_build_amp_sym(const T* __restrict__ shell, T* __restrict__ sym
 template <typename T>
 __device__ __forceinline__ T amp_at(const AmpSrc<T>& a, const KGeom& g, int i, int j, int l) {
     if (a.shell) return a.shell[shell_of(i, j, l, g.N)];
+    if (a.sym) {
+        const int mi = mode_of(i, g.N), mj = mode_of(j, g.N), ml = mode_of(l, g.N);
+        const int M = (g.N >> 1) + 1;
+        return a.sym[((long long)(mi < 0 ? -mi : mi) * M + (mj < 0 ? -mj : mj)) * g.NZP + (ml < 0 ? -ml : ml)];
+    }
     return a.dense[((long long)i * g.NR + j) * g.NZP + l];
 }
 

@@ -38,6 +38,7 @@ struct fb_plan {
     void* pca_work = nullptr;    // channel-sum / covariance partials (grown on demand)
     size_t pca_work_cap = 0;
     double* kperp_tab = nullptr; // [N][N] 2 pi sqrt((m_x/L_x)^2 + (m_y/L_y)^2), box.py:374
+    int amp_sym_only = 0;        // amp_sym was given directly (any box shape); no shell table behind it
     void* amp_sym = nullptr;     // [N/2+1][N/2+1][NZP] plan precision: amp_shell spread over (|m_x|, |m_y|, k_z)
 
     // P(k) binning (box.py:745-764)
@@ -102,6 +103,7 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_fft_r2c_##sfx(fb_plan* p, const void* real_in, void* half_out, int pre_exp, hipStream_t s); \
     int fbi_fft_c2r_##sfx(fb_plan* p, void* half_inout, void* real_out, double scale, hipStream_t s); \
     int fbi_set_amp_shells_##sfx(fb_plan* p, const double* amp, int64_t n); \
+    int fbi_set_amp_sym_##sfx(fb_plan* p, const double* amp, int64_t n); \
     int fbi_colour_noise_##sfx(fb_plan* p, const void* re, const void* im, void* out, hipStream_t s); \
     int fbi_colour_device_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* out, hipStream_t s); \
     int fbi_power_filtered_##sfx(fb_plan* p, const void* real_in, void* filtered_half, int kind, const double* prm, \

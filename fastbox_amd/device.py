@@ -313,6 +313,12 @@ class Engine(object):
         self._amp_dense = None
         _lib.call("fb_set_amplitude_shells", self._plan, amp.ctypes.data_as(_lib.P_double), amp.size)
 
+    def set_amplitude_sym(self, amp):
+        """sqrt(P boxfactor) per (|m_x|, |m_y|, |m_z|), shape (N/2+1,)*3: any box shape."""
+        amp = np.ascontiguousarray(amp, dtype=np.float64)
+        self._amp_dense = None
+        _lib.call("fb_set_amplitude_sym", self._plan, amp.ctypes.data_as(_lib.P_double), amp.size)
+
     def set_amplitude_dense(self, amp_half):
         """amp_half: host (N, N, N/2+1) array of sqrt(P boxfactor)."""
         N = self.N

@@ -69,6 +69,9 @@ int fb_fft_c2r(fb_plan* plan, void* half_inout, void* real_out, double scale, vo
 /* ---- Gaussian realisation (realise_density, box.py:161-187) --------------------------- */
 /* sqrt(nan_to_num(P(k)) * boxfactor): per integer shell n^2=i^2+j^2+l^2 (cubic boxes) ...   */
 int fb_set_amplitude_shells(fb_plan* plan, const double* amp, int64_t nshell);
+/* ... or, for any box shape, per (|m_x|, |m_y|, |m_z|): HOST double[M][M][M], M = N/2 + 1 (|k| depends on the mode
+ * numbers only through their magnitudes: an eighth of the modes to evaluate P(k) on) ...                     */
+int fb_set_amplitude_sym(fb_plan* plan, const double* amp, int64_t n);
 /* ... or per stored mode, a DEVICE array T[N][rows][pitch] (any box shape)                 */
 int fb_set_amplitude_dense(fb_plan* plan, const void* amp_dev);
 /* parity mode: re, im are the reference's np.random.normal draws, T[N][N][N] on the device  */
