@@ -72,27 +72,35 @@ __global__ __launch_bounds__(LPW * TPL) void k_proto(const cx<float>* __restrict
 #pragma unroll
         for (int e = 0; e < E; ++e) dst[t + e * TPL] = v[e];
     } else {
-        // one wave = one line; element e of lane t is k_z = t + 64 e: 64 consecutive k_z per e, n^2 range wave-uniform
+        // one wave = one line.  The bins the line can touch follow from its end points (n2row .. n2row + (N/2)^2);
+        // a mode's bin = blo + number of those thresholds it has reached; one pair of DPP sums per touched bin.
         const int n2row = kx * kx + my * my;
         const float w = (kx == 0 || kx == N / 2) ? 1.f : 2.f;
+        int blo = 0;
+        while (blo < nbins && lthr[blo] <= n2row) ++blo;
+        int bhi = blo;
+        while (bhi < nbins && lthr[bhi] <= n2row + (N / 2) * (N / 2)) ++bhi;
+        const int span = bhi - blo;                                    // <= 8 assumed by this prototype
+        int tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tv[u] = (u < span) ? lthr[blo + u] : 0x7fffffff;
+        float p[E]; int rel[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int kz = t + e * TPL, mz = kz < N / 2 ? kz : kz - N;
-            const int lo_m = e < 4 ? 64 * e : N - (64 * e + 63), hi_m = e < 4 ? 64 * e + 63 : N - 64 * e;   // |m_z| bounds
-            const int wlo = n2row + lo_m * lo_m, whi = n2row + hi_m * hi_m;
-            int blo = 0, bhi = 0;
-            while (blo < nbins && lthr[blo] <= wlo) ++blo;
-            bhi = blo;
-            while (bhi < nbins && lthr[bhi] <= whi) ++bhi;
-            const int edge = bhi > blo ? lthr[blo] : 0x7fffffff;
-            const float p = v[e].x * v[e].x + v[e].y * v[e].y;
-            const bool up = n2row + mz * mz >= edge;
-            const float s1 = wsum(up ? 0.f : w * p), s2 = wsum(up ? 0.f : w * p * p);
-            if (bhi > blo) {
-                const float u1 = wsum(up ? w * p : 0.f), u2 = wsum(up ? w * p * p : 0.f);
-                if (t == 0 && bhi < nbins) { acc[l][2 * bhi] += u1; acc[l][2 * bhi + 1] += u2; }
-            }
-            if (t == 0 && blo < nbins) { acc[l][2 * blo] += s1; acc[l][2 * blo + 1] += s2; }
+            const int n2 = n2row + mz * mz;
+            p[e] = w * (v[e].x * v[e].x + v[e].y * v[e].y);
+            int r = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r += (n2 >= tv[u]) ? 1 : 0;
+            rel[e] = r;
+        }
+        for (int u = 0; u <= span; ++u) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const bool in = rel[e] == u; s1 += in ? p[e] : 0.f; s2 += in ? p[e] * p[e] : 0.f; }
+            s1 = wsum(s1); s2 = wsum(s2);
+            if (t == 0 && blo + u < nbins) { acc[l][2 * (blo + u)] += s1; acc[l][2 * (blo + u) + 1] += s2; }
         }
         __syncthreads();
         if (tid < 2 * nbins) partial[(size_t)tid * gridDim.x + blockIdx.x] = acc[0][tid] + acc[1][tid] + acc[2][tid] + acc[3][tid];
