@@ -37,7 +37,11 @@ CASES = [
     ("n64_l100", 64, (1e2, 1e2, 1e2), 0.0, 11, 4, "pk"),
     ("n64_l4000", 64, 4e3, 0.8, 10, 4, "pk"),
     ("n128_l1000", 128, 1e3, 0.0, 14, 8, "pk"),
+    ("n256_l1000", 256, 1e3, 0.0, 14, 16, "pk"),
 ]
+
+
+ONLY = set(sys.argv[1:])          # python -m oracle.make_golden [case ...]: default all
 
 
 def probe(a, s):
@@ -98,7 +102,8 @@ def main():
     ref = load_reference_box()
     os.makedirs(OUT, exist_ok=True)
     for case in CASES:
-        capture(ref, *case)
+        if not ONLY or case[0] in ONLY:
+            capture(ref, *case)
 
 
 if __name__ == "__main__":
