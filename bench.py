@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--nbins", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-nsamp", type=int, default=256)
+    ap.add_argument("--cpu-nsamp", type=int, default=0,
+                    help="grid of the CPU baseline sample; 0 = the benchmarked size itself up to 512^3 (one step, "
+                         "~23 s of one host core), 256^3 scaled by voxel count above that")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "slab"],
                     help="replicas: every rank realises its own boxes (Monte-Carlo throughput, weak scaling; default). "
                          "slab: ONE box of --nsamp^3 spread over the ranks, slab-decomposed FFT with one RCCL "
@@ -70,10 +72,11 @@ def cpu_baseline(nsamp_bench, nsamp_cpu, nbins):
     bo.binned_power_spectrum(geo, np.fft.fftn(ln), nbins=nbins)
     dt = time.time() - t0
     scale = (nsamp_bench / float(nsamp_cpu)) ** 3
+    how = "the workload's own size, not scaled" if nsamp_cpu == nsamp_bench else \
+        "scaled by voxel count x%.0f to %d^3" % (scale, nsamp_bench)
     return {"value": 1.0 / (dt * scale), "unit": "boxes/s", "cores": 1, "kind": "port",
             "sample": "one %d^3 realise_density + lognormal + binned_power_spectrum with the numpy oracle "
-                      "(%.1f s, 1 thread), scaled by voxel count x%.0f to %d^3"
-                      % (nsamp_cpu, dt, scale, nsamp_bench)}
+                      "(%.1f s, 1 thread), %s" % (nsamp_cpu, dt, how)}
 
 
 def main():
@@ -184,7 +187,7 @@ def main():
                                      "achieved": 5.0 * sweep * boxes_per_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": 5.0 * sweep * boxes_per_s / 1e9 / HBM_PEAK_GBS}
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(N, args.cpu_nsamp, args.nbins)
+            line["cpu_baseline"] = cpu_baseline(N, args.cpu_nsamp or (N if N <= 512 else 256), args.nbins)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
