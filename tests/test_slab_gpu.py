@@ -130,3 +130,35 @@ def test_two_processes_one_gpu_host_staged_exchange(tmp_path):
     m = ~np.isnan(want[1])
     for g in got:
         assert np.allclose(g["pk"][1][m], want[1][m], rtol=1e-5, atol=0)
+
+
+def test_rccl_backend_single_rank_collectives():
+    """The collectives SlabBox issues (all_to_all_single, all_reduce) through torch's nccl backend (= RCCL) on this
+    GPU, world size 1: the transport this pool cannot exercise across GPUs at least loads and runs."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    try:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    except Exception as e:                                     # no RCCL in this environment: not this library's failure
+        pytest.skip("nccl backend unavailable: %s" % e)
+    try:
+        from fastbox_amd import default_cosmo
+        from fastbox_amd.distributed import SlabBox
+        x = torch.arange(1024, dtype=torch.float32, device="cuda")
+        y = torch.empty_like(x)
+        dist.all_to_all_single(y, x)
+        assert torch.equal(x, y)
+        r = torch.ones(41, dtype=torch.float64, device="cuda")
+        dist.all_reduce(r)
+        assert float(r.sum()) == 41.0
+        box = SlabBox(default_cosmo, box_scale=1e3, nsamp=64, precision="f32", seed=3, device=0)   # rank / world from the group
+        assert (box.rank, box.world) == (0, 1)
+        kc, pk, err = box.realise_and_power(nbins=20, lognormal=True)
+        assert np.all(np.isfinite(pk[~np.isnan(pk)]))
+    finally:
+        dist.destroy_process_group()
