@@ -21,9 +21,12 @@ def main():
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     import torch
+    backend = os.environ.get("FASTBOX_BENCH_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")   # as bench.py
+    if os.environ.get("FASTBOX_BENCH_ONE_DEVICE"):
+        local = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend)
     from fastbox_amd import CosmoBox, default_cosmo
     box = CosmoBox(default_cosmo, box_scale=1e3, nsamp=args.nsamp, realise_now=False, rng="device",
                    seed=7000 + rank, device=local)
@@ -50,12 +53,14 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:          # combine (n, mean, M2) of the ranks: Chan et al. pairwise update via raw sums
         s = torch.tensor(np.concatenate([[n, dt], n * mean, (m2 + n * np.outer(mean, mean)).ravel()]))
-        if torch.cuda.is_available():
+        if backend == "nccl":
             s = s.cuda(local)
         dist.all_reduce(s)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=s.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())                                       # the slowest rank
         s = s.cpu().numpy()
         nt = s[0]
-        dt = max(dt, 0.0)
         mean = s[2:2 + mean.size] / nt
         m2 = s[2 + mean.size:].reshape(m2.shape) - nt * np.outer(mean, mean)
         n = int(nt)
@@ -65,7 +70,7 @@ def main():
         ok = sig > 0
         corr = cov[np.ix_(ok, ok)] / np.outer(sig[ok], sig[ok])
         off = corr[~np.eye(corr.shape[0], dtype=bool)]
-        print("N=%d  %d realisations on %d GPU(s): %.1f s  (%.2f boxes/s)" % (args.nsamp, n, world, dt, n / dt))
+        print("N=%d  %d realisations on %d GPU(s): %.2f s  (%.2f boxes/s)" % (args.nsamp, n, world, dt, n / dt))
         print("k centres        :", np.array2string(kc[ok][:6], precision=4), "...")
         print("mean P(k)        :", np.array2string(mean[ok][:6], precision=4), "...")
         print("sigma/P          :", np.array2string((sig[ok] / mean[ok])[:6], precision=3), "...")
