@@ -38,6 +38,8 @@ CASES = [
     ("n64_l4000", 64, 4e3, 0.8, 10, 4, "pk"),
     ("n128_l1000", 128, 1e3, 0.0, 14, 8, "pk"),
     ("n256_l1000", 256, 1e3, 0.0, 14, 16, "pk"),
+    # BASELINE.json configs[1] (the size the metric is quoted on): ~25 GB and ~10 min of host work
+    ("n512_l1000", 512, 1e3, 0.0, 14, 32, "pkln"),
 ]
 
 
@@ -75,6 +77,11 @@ def capture(ref, name, N, box_scale, redshift, seed, s, what):
     out["freq_array"] = box.freq_array()
     ax, ay = box.pixel_array(redshift=max(redshift, 0.5))
     out["pixel_x"], out["pixel_y"] = ax, ay
+    if what == "pkln":
+        ln = box.lognormal(box.delta_x)
+        out["lognormal"] = probe(ln, s)
+        out["lognormal_mean_exp"] = np.mean(np.exp(box.delta_x))
+        out["pkln_k"], out["pkln_p"], out["pkln_e"] = box.binned_power_spectrum(delta_x=ln)
     if what == "all":
         ln = box.lognormal(box.delta_x)
         out["lognormal"] = probe(ln, s)

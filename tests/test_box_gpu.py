@@ -452,3 +452,30 @@ def test_deferred_realisation_fused_z_pass(precision, lognormal):
     tol = 2e-6 if precision == "f32" else 1e-12
     assert np.max(np.abs(np.asarray(dxa) - hb)) <= tol * np.std(hb)
     assert np.array_equal(pka[0], pkb[0]) and _pk_close(pka[1:], pkb[1:], 20 * tol)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_headline_size_against_the_reference(golden_dir, precision):
+    """BASELINE.json configs[1] (512^3, Gaussian + log-normal + P(k)) against vectors the reference
+    itself produced at that size (oracle/make_golden.py n512_l1000): same seeded numpy noise in,
+    fields on the probe sub-lattice and every binned spectrum out."""
+    g = _load(golden_dir, "n512_l1000")
+    s = int(g["stride"])
+    ftol, ptol = FIELD_TOL[precision], PK_TOL[precision]
+    box = _box(g, precision)
+    dx = box.realise_density()
+    assert dx.shape == (512, 512, 512)
+    assert _field_close(np.asarray(dx[::s, ::s, ::s]), g["delta_x"], ftol)
+    assert _field_close(np.asarray(box.delta_k[::s, ::s, ::s]), g["delta_k"], ftol)
+    assert np.isclose(float(np.sum(dx ** 2.)), float(g["delta_x_sumsq"]), rtol=ptol)
+    for nb in (20, 50):
+        kc, pk, err = box.binned_power_spectrum(nbins=nb)
+        assert np.array_equal(kc, g["pk%d_k" % nb])
+        assert _pk_close((pk, err), (g["pk%d_p" % nb], g["pk%d_e" % nb]), ptol)
+    kc, pk, err = box.binned_power_spectrum(kbins=g["kbins"])
+    assert _pk_close((pk, err), (g["pkkb_p"], g["pkkb_e"]), ptol)
+    ln = box.lognormal(dx)
+    assert _field_close(np.asarray(ln[::s, ::s, ::s]), g["lognormal"], 5 * ftol)
+    kc, pk, err = box.binned_power_spectrum(delta_x=ln)
+    assert np.array_equal(kc, g["pkln_k"])
+    assert _pk_close((pk, err), (g["pkln_p"], g["pkln_e"]), 3 * ptol)

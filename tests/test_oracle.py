@@ -86,6 +86,23 @@ def test_derived_fields(golden_dir, name):
     assert _same(pk, g["pkrsd_p"])
 
 
+@pytest.mark.skipif(os.environ.get("FASTBOX_SLOW_TESTS", "0") != "1",
+                    reason="~3 min and ~20 GB of host work: set FASTBOX_SLOW_TESTS=1")
+def test_oracle_at_the_headline_size(golden_dir):
+    """BASELINE.json configs[1]: the oracle against what the reference produced at 512^3."""
+    g = _load(golden_dir, "n512_l1000")
+    geo, cosmo, a, rng, dx, dk = _realise(g)
+    s = int(g["stride"])
+    assert _same(dx[::s, ::s, ::s], g["delta_x"]) and _same(dk[::s, ::s, ::s], g["delta_k"])
+    assert np.sum(dx) == float(g["delta_x_sum"])
+    kc, pk, err = bo.binned_power_spectrum(geo, dk, nbins=20)
+    assert _same(kc, g["pk20_k"]) and _same(pk, g["pk20_p"]) and _same(err, g["pk20_e"])
+    ln = bo.lognormal(dx)
+    assert _same(ln[::s, ::s, ::s], g["lognormal"])
+    kc, pk, err = bo.binned_power_spectrum(geo, np.fft.fftn(ln))
+    assert _same(pk, g["pkln_p"]) and _same(err, g["pkln_e"])
+
+
 def test_oracle_against_live_reference():
     """When the reference is on this machine, compare directly on a fresh seed."""
     from oracle import ref_loader
