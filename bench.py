@@ -147,7 +147,9 @@ def main():
         # writes N*N*(N/2+1) complex values once each (DESIGN.md "Algorithmic bytes")
         s = 4 if args.precision == "f32" else 8
         ms, launches = prof["fft_strided"]
-        alg_bytes = 2.0 * N * N * (N // 2 + 1) * 2 * s
+        # a step holds two such passes (inverse and forward y); each is launched once per x-plane batch
+        # (fb_fft_launch.inc yz_passes), so one launch moves its share of the two passes' bytes
+        alg_bytes = 2 * (2.0 * N * N * (N // 2 + 1) * 2 * s) * args.steps / max(launches, 1)
         achieved = alg_bytes / (ms / max(launches, 1) * 1e-3) / 1e9 if ms > 0 else None
         total_ms = sum(v[0] for v in prof.values())
         # HBM traffic of the same kernel from the PMC counters: collected off-line in two separate

@@ -99,6 +99,9 @@ int fb_plan_destroy(fb_plan* p) {
     void* ptrs[] = {p->tw, p->axis2, p->ksc, p->kpar, p->zgrid, p->amp_shell, p->amp_sym, p->kperp_tab, p->pca_work, p->bins, p->thr, p->counts,
                     p->partials, p->scratch, p->bin_partials, p->exp_partials};
     for (void* q : ptrs) if (q) (void)hipFree(q);
+    if (p->aux_stream) { (void)hipStreamSynchronize(p->aux_stream); (void)hipStreamDestroy(p->aux_stream); }
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     delete p;
     return FB_OK;
 }

@@ -59,6 +59,11 @@ struct fb_plan {
     double* exp_partials = nullptr;   // r2c with exp(): [workgroups]
     size_t exp_partials_cap = 0;
     long long exp_rows = 0;
+    long long exp_base = 0;           // block offset of the plane batch being launched (fb_fft_launch.inc yz_passes)
+
+    // second stream for alternate plane batches of the y/z passes (created on first use)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // per-kernel HIP-event timing (fb_profile_start / fb_profile_stop)
     bool prof_on = false;

@@ -437,7 +437,7 @@ class Engine(object):
         return out
 
     def realise_begin(self, seed, realisation):
-        """Generator + x and y passes; returns the pending half spectrum (z pass still to do)."""
+        """Generator + x pass; returns the pending half spectrum (y and z passes still to do)."""
         pend = self.empty(HALF)
         _lib.call("fb_realise_density_begin", self._plan, int(seed) & (2 ** 64 - 1),
                   int(realisation) & (2 ** 64 - 1), pend.ptr, self.stream)

@@ -91,10 +91,13 @@ int fb_realise_density_device(fb_plan* plan, uint64_t seed, uint64_t realisation
 int fb_realise_velocity_device(fb_plan* plan, uint64_t seed, uint64_t realisation, int comp, double fac,
                                void* work_half, void* real_out, void* stream);
 
-/* deferred form of the above: _begin runs the generator + x and y passes into `pending_half`
- * (half-spectrum sized); the z pass is done later by _finish (real_out = delta_x), or by
- * fb_power_spectrum_pending, which fuses it with the first pass of the power spectrum: real_out is
- * written (delta_x is still produced) but never read back.                                      */
+/* deferred form of the above: _begin runs the generator + x pass into `pending_half` (half-spectrum
+ * sized); the y and z passes are done later by _finish (real_out = delta_x), or by
+ * fb_power_spectrum_pending, which fuses the z pass with the first pass of the power spectrum:
+ * real_out is written (delta_x is still produced) but never read back.  The y and z passes of every
+ * transform run x-plane batch by x-plane batch, so that a batch stays in the Infinity Cache between
+ * them (env FB_PLANE_BATCH = planes per batch, 0 = off; FB_PLANE_STREAMS = 2 adds a plan-owned
+ * auxiliary stream for alternate batches, joined back into `stream` before the call returns).   */
 int fb_realise_density_begin(fb_plan* plan, uint64_t seed, uint64_t realisation, void* pending_half, void* stream);
 int fb_realise_density_finish(fb_plan* plan, void* pending_half, void* real_out, void* stream);
 
