@@ -157,7 +157,7 @@ def main():
         # profiles/; FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md (HBM).
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_summary.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_fetch_write_summary.json")))
             key = [k for k in pmc if "k_fft_strided<float, %d, 0" % N in k]
             if key and args.precision == "f32":
                 c = pmc[key[0]]
