@@ -732,11 +732,26 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
             for (int e = 0; e < E; ++e) nz[e] = los_noise_at<T>(idx0 + e, rkey);
         }
     }
+    // this lane's E consecutive velocities and densities in 16-byte loads (a lane's cells are contiguous)
+    T vin[E];
+    if constexpr (E * sizeof(T) % 16 == 0) {
+        typedef T vec16 __attribute__((ext_vector_type(16 / sizeof(T))));
+        constexpr int PER = 16 / sizeof(T);
+#pragma unroll
+        for (int q = 0; q < E / PER; ++q) {
+            const vec16 a = reinterpret_cast<const vec16*>(v + lane * E)[q], b = reinterpret_cast<const vec16*>(d + lane * E)[q];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) { vin[q * PER + u] = a[u]; val[q * PER + u] = b[u]; }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { vin[e] = v[lane * E + e]; val[e] = d[lane * E + e]; }
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
 #pragma clang fp contract(off)
         const int m = lane * E + e;
-        double vel = (double)v[m];
+        double vel = (double)vin[e];
         if (sigma_nl > 0.0) vel = vel + sigma_nl * (double)nz[e];
         double r;
         if constexpr (sizeof(T) == 4) {
@@ -764,7 +779,6 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         }
         kb[e] = order_bits(key);
         cell[e] = c;
-        val[e] = d[m];
         atomicMax(&kex[c], kb[e]);
     }
     __syncthreads();
