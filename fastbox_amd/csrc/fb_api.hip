@@ -353,6 +353,18 @@ int fb_mask_transverse(fb_plan* p, void* full_cube, const void* mask2d, void* st
     return FB_DISPATCH(p, fbi_mask_xy_f32(p, full_cube, mask2d, s), fbi_mask_xy_f64(p, full_cube, mask2d, s));
 }
 
+// ---- beam convolution (fastbox/beams.py:63-137) ---------------------------------------------------------------
+int fb_beam_convolve(fb_plan* p, const void* field, const void* beam, void* work_a, void* work_b, void* out, int periodic,
+                     void* stream) {
+    FB_REQUIRE(p && field && beam && work_a && work_b && out, "null pointer");
+    FB_REQUIRE(work_a != work_b, "the two work cubes must be distinct");
+    FB_REQUIRE(periodic == 0 || periodic == 1, "periodic must be 0 or 1");
+    FB_REQUIRE(periodic || p->N >= 32, "zero-padded convolution: the plan is that of the transform size 2n >= 32");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_beam_convolve_f32(p, field, beam, work_a, work_b, out, periodic, s),
+                       fbi_beam_convolve_f64(p, field, beam, work_a, work_b, out, periodic, s));
+}
+
 // ---- PCA foreground cleaning (fastbox/filters.py:93-183) -----------------------------------------------------
 int fb_channel_means(fb_plan* p, const void* cube, double* mean_dev, void* stream) {
     FB_REQUIRE(p && cube && mean_dev, "null pointer");

@@ -980,6 +980,36 @@ __global__ __launch_bounds__(256) void k_mask_xy(cx<T>* __restrict__ cube, const
     }
 }
 
+// ---- beam convolution (fastbox/beams.py:63-137): per-channel 2-D convolution of a field with a beam cube, through an
+// M x M transverse transform of both (M = 2n zero-padded for scipy.signal.fftconvolve's linear convolution, M = n for
+// convolve2d's boundary='wrap').  One (x, y) row of the M x M grid per workgroup, the n channels contiguous. ---------
+template <typename T>
+__global__ __launch_bounds__(256) void k_beam_embed(const T* __restrict__ in, cx<T>* __restrict__ out, int n, int M) {
+    const long long row = blockIdx.x;
+    const int x = (int)(row / M), y = (int)(row % M);
+    const bool inside = x < n && y < n;                   // block-uniform
+    const T* src = in + ((long long)(inside ? x : 0) * n + (inside ? y : 0)) * n;
+    for (int z = threadIdx.x; z < n; z += blockDim.x) out[row * n + z] = cx<T>{inside ? src[z] : (T)0, (T)0};
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_beam_multiply(cx<T>* __restrict__ a, const cx<T>* __restrict__ b, long long count) {
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += step) {
+        const cx<T> u = a[i], v = b[i];
+        a[i] = cx<T>{u.x * v.x - u.y * v.y, u.x * v.y + u.y * v.x};
+    }
+}
+// mode='same': out[i, j, z] = conv[(i + off) mod M, (j + off) mod M, z] / sum_xy beam[:, :, z]; the sum is the beam's
+// own (k_x, k_y) = (0, 0) coefficient, beam_k[z]
+template <typename T>
+__global__ __launch_bounds__(256) void k_beam_crop(const cx<T>* __restrict__ conv, const cx<T>* __restrict__ beam_k,
+                                                   T* __restrict__ out, int n, int M, int off) {
+    const long long row = blockIdx.x;                     // (i, j) of the n x n output
+    const int i = (int)(row / n), j = (int)(row % n);
+    const long long src = ((long long)((i + off) % M) * M + (j + off) % M) * n;
+    for (int z = threadIdx.x; z < n; z += blockDim.x) out[row * n + z] = conv[src + z].x / beam_k[z].x;
+}
+
 // ---- PCA foreground cleaning (fastbox/filters.py:93-183): channel means, frequency-frequency covariance,
 // projection onto the leading modes.  The cube is T[pixel = (x, y)][channel] with the channel contiguous. ----------
 

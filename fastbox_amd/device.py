@@ -181,6 +181,7 @@ class Engine(object):
         self.lib = _lib.load()
         self.N = int(N)
         self.precision = precision
+        self.device = int(device)
         self.rdtype = np.float32 if precision == "f32" else np.float64
         self.cdtype = np.complex64 if precision == "f32" else np.complex128
         self.stream = ctypes.c_void_p(stream) if stream else None

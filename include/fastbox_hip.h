@@ -198,6 +198,15 @@ int fb_real_to_complex(fb_plan* plan, const void* real_cube, void* full_cube, vo
 int fb_fft_transverse(fb_plan* plan, void* full_cube, int direction, void* stream);
 int fb_mask_transverse(fb_plan* plan, void* full_cube, const void* mask2d, void* stream);
 
+/* ---- beam convolution, channel by channel (BeamModel.convolve_fft / convolve_real, fastbox/beams.py:63-137) ----
+ * out[n][n][n] = (field (*) beam)[mode='same'] / sum_xy beam, for real cubes field, beam of T[n][n][n] (frequency =
+ * last axis).  `plan` is the plan of the TRANSFORM size M = plan N: periodic = 0: M = 2 n, zero-padded linear
+ * convolution = scipy.signal.fftconvolve(beam, field, mode='same', axes=[0, 1]) (:85-87); periodic = 1: M = n,
+ * circular convolution = scipy.signal.convolve2d(beam[:, :, i], field[:, :, i], mode='same', boundary='wrap')
+ * (:134-136).  work_a, work_b: distinct device buffers of complex<T>[M][M][n].                                      */
+int fb_beam_convolve(fb_plan* plan, const void* field, const void* beam, void* work_a, void* work_b, void* out,
+                     int periodic, void* stream);
+
 /* ---- PCA foreground cleaning of a data cube T[N][N][N] (frequency = last axis), fastbox/filters.py:93-183 ----
  * mean_dev[N]: per-channel mean over the N^2 pixels (:142), fp64 on the DEVICE.                                   */
 int fb_channel_means(fb_plan* plan, const void* cube, double* mean_dev, void* stream);

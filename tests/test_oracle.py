@@ -187,3 +187,21 @@ def test_host_side_helpers_of_the_sky_models_match_the_oracle():
         w, r = sky._gaussian_weights(sigma)
         wo, ro = so.gaussian_weights(sigma)
         assert r == ro and np.array_equal(w, wo) and abs(w.sum() - 1) < 1e-15
+
+
+@pytest.mark.parametrize("name", ["beam_n16", "beam_n32"])
+def test_beam_oracle_reproduces_reference_vectors(golden_dir, name):
+    """oracle/beam_oracle.py against BeamModel.convolve_fft / convolve_real run by the reference itself
+    (oracle/make_golden_beams.py).  scipy's fftconvolve uses real transforms of another length and convolve2d a
+    direct sum, so agreement is to rounding (1e-12 of the field's scale), not bit for bit."""
+    from oracle import beam_oracle as bo_beam
+    g = _load(golden_dir, name)
+    beam, field = g["beam"], g["field"]
+    scale = np.max(np.abs(g["conv_fft"]))
+    assert np.max(np.abs(bo_beam.convolve_fft(beam, field) - g["conv_fft"])) < 1e-12 * scale
+    assert np.max(np.abs(bo_beam.convolve_fft(np.ones_like(beam), field) - g["conv_fft_uniform"])) < 1e-12 * scale
+    if "conv_real" in g.files:
+        assert np.max(np.abs(bo_beam.convolve_real_direct(beam, field) - g["conv_real"])) < 1e-12 * scale
+        assert np.max(np.abs(bo_beam.convolve_real(beam, field) - g["conv_real"])) < 1e-12 * scale
+    # the fixture's beam is an input produced by the oracle module: it must regenerate from the stored grid
+    assert g["beam"].shape == field.shape
