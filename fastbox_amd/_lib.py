@@ -65,7 +65,7 @@ SIGNATURES = {
     "fb_real_to_complex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_fft_transverse": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "fb_mask_transverse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
-    "fb_beam_convolve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "fb_beam_convolve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fb_channel_means": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_channel_covariance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_pca_clean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -56,14 +56,26 @@ class BeamModel(object):
         if field.kind != REAL:
             raise TypeError("expected a real-space cube")
         beam = self.beam_cube(pol=pol) if pol is not None else self.beam_cube()
-        beam = beam if isinstance(beam, DeviceArray) else box._as_real(beam)
         M = n if periodic else 2 * n
         big = self._transform_engine(M)
         nbytes = M * M * n * np.dtype(eng.cdtype).itemsize
-        work_a, work_b = big._alloc_bytes(nbytes), big._alloc_bytes(nbytes)
+        work_a = big._alloc_bytes(nbytes)
+        # the transform of a beam cube is kept with the cube it came from: the same array object (host or device) on
+        # the next call skips its embedding and forward transform
+        cached = self.__dict__.get("_beam_k")
+        ready = cached is not None and cached[0] is beam and cached[1] == (M, periodic)
+        if ready:
+            work_b = cached[2]
+            beam_ptr = None
+        else:
+            self._beam_k = None
+            work_b = big._alloc_bytes(nbytes)
+            beam_dev = beam if isinstance(beam, DeviceArray) else box._as_real(beam)
+            beam_ptr = beam_dev.ptr
         out = eng.empty(REAL)
-        _lib.call("fb_beam_convolve", big._plan, field.ptr, beam.ptr, work_a.ptr, work_b.ptr, out.ptr,
-                  1 if periodic else 0, eng.stream)
+        _lib.call("fb_beam_convolve", big._plan, field.ptr, beam_ptr, work_a.ptr, work_b.ptr, out.ptr,
+                  1 if periodic else 0, 1 if ready else 0, eng.stream)
+        self._beam_k = (beam, (M, periodic), work_b)
         return out
 
     def convolve_fft(self, field_x, pol=None):

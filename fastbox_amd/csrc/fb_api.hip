@@ -355,14 +355,16 @@ int fb_mask_transverse(fb_plan* p, void* full_cube, const void* mask2d, void* st
 
 // ---- beam convolution (fastbox/beams.py:63-137) ---------------------------------------------------------------
 int fb_beam_convolve(fb_plan* p, const void* field, const void* beam, void* work_a, void* work_b, void* out, int periodic,
-                     void* stream) {
-    FB_REQUIRE(p && field && beam && work_a && work_b && out, "null pointer");
+                     int beam_ready, void* stream) {
+    FB_REQUIRE(p && field && work_a && work_b && out, "null pointer");
+    FB_REQUIRE(beam || beam_ready, "null beam cube");
     FB_REQUIRE(work_a != work_b, "the two work cubes must be distinct");
-    FB_REQUIRE(periodic == 0 || periodic == 1, "periodic must be 0 or 1");
+    FB_REQUIRE((periodic == 0 || periodic == 1) && (beam_ready == 0 || beam_ready == 1), "periodic, beam_ready must be 0 or 1");
     FB_REQUIRE(periodic || p->N >= 32, "zero-padded convolution: the plan is that of the transform size 2n >= 32");
     hipStream_t s = (hipStream_t)stream;
-    return FB_DISPATCH(p, fbi_beam_convolve_f32(p, field, beam, work_a, work_b, out, periodic, s),
-                       fbi_beam_convolve_f64(p, field, beam, work_a, work_b, out, periodic, s));
+    const int flags = periodic | (beam_ready << 1);
+    return FB_DISPATCH(p, fbi_beam_convolve_f32(p, field, beam, work_a, work_b, out, flags, s),
+                       fbi_beam_convolve_f64(p, field, beam, work_a, work_b, out, flags, s));
 }
 
 // ---- PCA foreground cleaning (fastbox/filters.py:93-183) -----------------------------------------------------

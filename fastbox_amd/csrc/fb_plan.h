@@ -127,7 +127,7 @@ int fb_hip_check(hipError_t e, const char* what);
                              int mul, hipStream_t s); \
     int fbi_fft_axes01_##sfx(fb_plan* p, void* data, int sign, double scale, hipStream_t s); \
     int fbi_beam_convolve_##sfx(fb_plan* p, const void* field, const void* beam, void* work_a, void* work_b, void* out, \
-                                int periodic, hipStream_t s); \
+                                int flags, hipStream_t s); \
     int fbi_real_to_complex_##sfx(fb_plan* p, const void* in, void* out, hipStream_t s); \
     int fbi_mask_xy_##sfx(fb_plan* p, void* cube, const void* mask2d, hipStream_t s); \
     int fbi_fft2d_c2c_##sfx(fb_plan* p, void* data, int sign, double scale, hipStream_t s); \

@@ -203,9 +203,10 @@ int fb_mask_transverse(fb_plan* plan, void* full_cube, const void* mask2d, void*
  * last axis).  `plan` is the plan of the TRANSFORM size M = plan N: periodic = 0: M = 2 n, zero-padded linear
  * convolution = scipy.signal.fftconvolve(beam, field, mode='same', axes=[0, 1]) (:85-87); periodic = 1: M = n,
  * circular convolution = scipy.signal.convolve2d(beam[:, :, i], field[:, :, i], mode='same', boundary='wrap')
- * (:134-136).  work_a, work_b: distinct device buffers of complex<T>[M][M][n].                                      */
+ * (:134-136).  work_a, work_b: distinct device buffers of complex<T>[M][M][n].  work_b holds the beam's transform
+ * afterwards: beam_ready = 1 on a later call with the same plan, mode and work_b reuses it (beam is then ignored). */
 int fb_beam_convolve(fb_plan* plan, const void* field, const void* beam, void* work_a, void* work_b, void* out,
-                     int periodic, void* stream);
+                     int periodic, int beam_ready, void* stream);
 
 /* ---- PCA foreground cleaning of a data cube T[N][N][N] (frequency = last axis), fastbox/filters.py:93-183 ----
  * mean_dev[N]: per-channel mean over the N^2 pixels (:142), fp64 on the DEVICE.                                   */

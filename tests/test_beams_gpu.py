@@ -11,6 +11,10 @@ from oracle import beam_oracle as bo       # noqa: E402
 from oracle import standin                  # noqa: E402
 
 
+def g_beam_of(model):
+    return model.beam_cube()
+
+
 def _case(golden_dir, name, precision):
     from fastbox_amd import BeamModel, CosmoBox
     g = np.load(os.path.join(golden_dir, name + ".npz"))
@@ -35,6 +39,8 @@ def test_beam_convolution_matches_reference_vectors(golden_dir, name, precision,
     out = beam.convolve_fft(field)
     assert out.shape == field.shape and out.dtype == np.float64
     assert np.max(np.abs(np.asarray(out) - g["conv_fft"])) < tol * scale
+    again = beam.convolve_fft(2. * field)              # same beam object: its transform is reused
+    assert beam._beam_k[0] is g_beam_of(beam) and np.max(np.abs(np.asarray(again) - 2. * g["conv_fft"])) < 2 * tol * scale
     # a device cube in, the base class's uniform beam (beams.py:26-38)
     dev_field = box.engine.upload(field, "real")
     assert np.max(np.abs(np.asarray(BeamModel(box).convolve_fft(dev_field)) - g["conv_fft_uniform"])) < tol * scale
