@@ -90,6 +90,7 @@ SIGNATURES = {
     "fb_debug_strided_pass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fb_debug_read_stamps": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), c_i64]),
     "fb_profile_select": (c_int, [c_void_p, ctypes.c_uint]),
+    "fb_profile_sample": (c_int, [c_void_p, c_int, ctypes.POINTER(c_i64)]),
     "fb_profile_start": (c_int, [c_void_p]),
     "fb_profile_stop": (c_int, [c_void_p, c_void_p, P_double, ctypes.POINTER(c_i64), c_int]),
     "fb_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size_t]),

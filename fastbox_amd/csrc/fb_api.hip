@@ -542,8 +542,16 @@ int fb_profile_select(fb_plan* p, unsigned mask) {
     p->prof_mask = mask;
     return FB_OK;
 }
+int fb_profile_sample(fb_plan* p, int stride, int64_t* seen) {
+    FB_REQUIRE(p, "null pointer");
+    FB_REQUIRE(stride >= 1, "stride must be >= 1");
+    if (seen) *seen = (int64_t)p->prof_seen;
+    p->prof_stride = stride;
+    return FB_OK;
+}
 int fb_profile_start(fb_plan* p) {
     FB_REQUIRE(p, "null pointer");
+    p->prof_seen = 0;
     p->prof_used = 0;
     p->prof_cat.clear();
     p->prof_on = true;

@@ -68,6 +68,8 @@ struct fb_plan {
     // per-kernel HIP-event timing (fb_profile_start / fb_profile_stop)
     bool prof_on = false;
     unsigned prof_mask = 0xFFFFFFFFu;   // kernel classes to bracket (bit = FBK_* index)
+    int prof_stride = 1;                // bracket every prof_stride-th selected launch (fb_profile_sample)
+    long long prof_seen = 0;            // selected launches since fb_profile_start
     std::vector<hipEvent_t> prof_ev;   // pairs
     std::vector<int> prof_cat;
     size_t prof_used = 0;
@@ -83,6 +85,7 @@ struct FbProfScope {
     FbProfScope(fb_plan* plan, int cat, hipStream_t stream)
         : p(plan), s(stream), slot(0), on(plan->prof_on && ((plan->prof_mask >> cat) & 1u)) {
         if (!on) return;
+        if ((p->prof_seen++ % p->prof_stride) != 0) { on = false; return; }
         if (p->prof_used + 2 > p->prof_ev.size()) {
             for (int q = 0; q < 64; ++q) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
                                            p->prof_ev.push_back(e); }

@@ -538,11 +538,19 @@ class Engine(object):
     PROF_NAMES = ("fft_strided", "fft_contig", "colour", "bin", "filter", "velpot", "realop", "rsd", "layout",
                   "fft_gen", "fft_bin", "pca")
 
-    def profile_start(self, only=None):
-        """Bracket kernel launches with HIP events; `only` = iterable of class names to restrict to."""
+    def profile_start(self, only=None, stride=1):
+        """Bracket kernel launches with HIP events; `only` = iterable of class names to restrict to; `stride` =
+        bracket every stride-th of those launches only (each event pair costs stream time)."""
         mask = 0xFFFFFFFF if only is None else sum(1 << self.PROF_NAMES.index(n) for n in only)
         _lib.call("fb_profile_select", self._plan, mask)
+        _lib.call("fb_profile_sample", self._plan, int(stride), None)
         _lib.call("fb_profile_start", self._plan)
+
+    def profile_seen(self):
+        """Selected launches since profile_start (bracketed or not)."""
+        seen = ctypes.c_int64()
+        _lib.call("fb_profile_sample", self._plan, 1, ctypes.byref(seen))
+        return seen.value
 
     def profile_stop(self):
         """{kernel class: (total ms, launches)} measured with HIP events on the launch stream."""
