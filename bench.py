@@ -174,6 +174,17 @@ def main():
                 traffic = (2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024.0
         except Exception:
             traffic = None
+        # the committed rocprofv3 --kernel-trace --stats summary of this command, for the cross-check the two
+        # timings owe each other (the event bracket also holds the ~3 us between the event and the kernel's start)
+        rocprof_us = None
+        try:
+            import csv
+            with open(os.path.join(ROOT, "profiles", "r01g_kernel_stats.csv")) as fh:
+                for row in csv.DictReader(fh):
+                    if ("k_fft_strided<%s, %d, 0" % ("float" if s == 4 else "double", N)) in row["Name"]:
+                        rocprof_us = float(row["AverageNs"]) * 1e-3
+        except Exception:
+            rocprof_us = None
         line = {
             "metric": "%d^3 box realisations/sec (gen + log-normal + P(k))" % N,
             "value": world * args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps,
@@ -187,7 +198,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
                          "algorithmic_bytes": alg_bytes,
                          "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": plain_launches,
-                         "launches_timed": launches},
+                         "launches_timed": launches, "rocprof_avg_launch_us": rocprof_us},
             # (sampled brackets: scaled from the timed launches to all of them)
             "kernel_ms_per_step": {k: round(v[0] / args.steps * (plain_launches / max(v[1], 1) if ev_stride > 1 else 1.), 4)
                                    for k, v in prof.items() if v[1]},
