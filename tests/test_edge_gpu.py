@@ -108,6 +108,33 @@ def test_full_size_properties(N):
     assert box2.engine.sum_real(box2.realise_density(), squared=True) == box.engine.sum_real(dx, squared=True)
 
 
+def test_largest_size_properties():
+    """2048^3 (34 GB of field, 36 GB of spectrum per buffer): the largest grid the plans support, on one GPU."""
+    import gc
+    N = 2048
+    box = _box(N, 2e3, precision="f32", rng="device", seed=4)
+    dx = box.realise_density()
+    kc, pk, err = box.binned_power_spectrum(delta_x=dx, nbins=20)          # fused z passes + binning, plane batches
+    m = ~np.isnan(pk)
+    assert m.sum() >= 15 and np.all(pk[m] > 0) and np.all(err[m] >= 0)
+    s1, s2 = box.test_parseval()
+    assert np.isclose(s1, s2, rtol=2e-5)
+    mean = box.engine.sum_real(dx) / float(N) ** 3
+    assert abs(mean) < 1e-3
+    # the estimate follows the input spectrum where shells are complete and well sampled (the last bins reach into
+    # the corners of the cube beyond the Nyquist frequency); ~1 % low from averaging a falling P(k) over a wide bin
+    kt, pt = box.theoretical_power_spectrum()
+    ratio = pk[m][-9:-3] / np.interp(kc[m][-9:-3], kt, pt)
+    assert np.all((ratio > 0.95) & (ratio < 1.02)), ratio
+    sq = box.engine.sum_real(dx, squared=True)
+    del dx, box
+    gc.collect()
+    box2 = _box(N, 2e3, precision="f32", rng="device", seed=4)
+    assert box2.engine.sum_real(box2.realise_density(), squared=True) == sq          # bit-reproducible generator
+    del box2
+    gc.collect()
+
+
 def test_many_queued_spectra_come_back_in_batches():
     """wait=False results live in a ring of device records fetched in one copy per batch; queue more than
     the ring holds (256) before asking for any, read them out of order, compare with one-at-a-time."""
