@@ -13,6 +13,9 @@ void fb_set_error(const std::string& msg) { g_last_error = msg; }
 int fb_hip_check(hipError_t e, const char* what) {
     if (e == hipSuccess) return FB_OK;
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    // the runtime also keeps the error as its "last error": read it away, or the next launch check
+    // (hipGetLastError after a kernel launch) would report this failure a second time
+    (void)hipGetLastError();
     return e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP;
 }
 

@@ -172,6 +172,9 @@ def new_stream():
     return s.value
 
 
+_ENGINES = weakref.WeakSet()        # live engines (their idle-buffer pools are released when memory runs out)
+
+
 class Engine(object):
     """One fb_plan + buffer pool.  All field arguments are DeviceArrays."""
 
@@ -204,6 +207,7 @@ class Engine(object):
         self._res_next = 0          # serial of the next record to hand out
         self._res_fetched = 0       # records with serial < this are valid in _res_host (unless overwritten)
         self._res_waiters = {}      # serial -> weakref of the PendingSpectrum that wants the record
+        _ENGINES.add(self)
 
     def close(self):
         if getattr(self, "_plan", None) is not None and self._plan:
@@ -230,8 +234,26 @@ class Engine(object):
         if free:
             return _Buffer(free.pop(), nbytes, self._pool)
         p = ctypes.c_void_p()
-        _lib.call("fb_malloc", ctypes.byref(p), nbytes)
+        try:
+            _lib.call("fb_malloc", ctypes.byref(p), nbytes)
+        except _lib.FastBoxError as e:
+            if e.code != -4:                               # FB_ERR_NOMEM
+                raise
+            # out of device memory: drop what nobody uses any more -- engines of boxes that are gone (reference
+            # cycles keep them until a collection) and every live engine's cache of idle buffers -- and try once more
+            import gc
+            gc.collect()
+            self.sync()
+            for eng in list(_ENGINES):
+                eng.release_idle_buffers()
+            _lib.call("fb_malloc", ctypes.byref(p), nbytes)
         return _Buffer(p.value, nbytes, self._pool)
+
+    def release_idle_buffers(self):
+        """Give the pooled (currently unused) device buffers back to the driver."""
+        for ptrs in self._pool.values():
+            while ptrs:
+                self.lib.fb_free(ctypes.c_void_p(ptrs.pop()))
 
     def empty(self, kind, as_complex=False):
         return DeviceArray(self, kind, self._alloc_bytes(self.nbytes[kind]), as_complex)

@@ -146,3 +146,34 @@ def test_many_queued_spectra_come_back_in_batches():
     for i in range(300):
         want = box2.binned_power_spectrum(delta_x=box2.realise_density(), nbins=12)
         assert np.array_equal(got[i][1], want[1], equal_nan=True) and np.array_equal(got[i][2], want[2], equal_nan=True), i
+
+
+def test_out_of_memory_releases_idle_buffers_and_retries():
+    """hipMalloc failing is not final while engines hold pools of idle buffers (or dead boxes wait for a garbage
+    collection): those are released and the allocation is tried once more."""
+    import ctypes
+    from fastbox_amd import _lib as lib_mod
+    from fastbox_amd.device import _ENGINES
+    box = _box(256, 1e3, precision="f32", rng="device", seed=1)
+    eng = box.engine
+    buf = eng._alloc_bytes(1 << 20)
+    del buf                                              # -> idle in the pool
+    assert eng._pool[1 << 20]
+    real_call = lib_mod.call
+    state = {"failed": False}
+
+    def flaky(name, *args):                               # the first fb_malloc reports out of memory
+        if name == "fb_malloc" and not state["failed"]:
+            state["failed"] = True
+            raise lib_mod.FastBoxError("fb_malloc", -4, "out of memory (injected)")
+        return real_call(name, *args)
+
+    lib_mod.call = flaky
+    try:
+        again = eng._alloc_bytes(3 << 20)
+    finally:
+        lib_mod.call = real_call
+    assert state["failed"] and again.ptr and eng in _ENGINES
+    assert not eng._pool[1 << 20]                         # the idle buffer went back to the driver
+    dx = box.realise_density()                            # the engine is still good
+    assert np.isfinite(eng.sum_real(dx, squared=True))
