@@ -19,7 +19,9 @@ int fb_hip_check(hipError_t e, const char* what) {
     return e == hipErrorOutOfMemory ? FB_ERR_NOMEM : FB_ERR_HIP;
 }
 
-#define FB_REQUIRE(cond, msg) do { if (!(cond)) { fb_set_error(msg); return FB_ERR_INVALID; } } while (0)
+// (every entry point starts with an argument check: it also reads away a stale "last error" some other user of the
+// HIP runtime may have left in this thread, so that the launch checks below report this call's errors only)
+#define FB_REQUIRE(cond, msg) do { (void)hipGetLastError(); if (!(cond)) { fb_set_error(msg); return FB_ERR_INVALID; } } while (0)
 #define FB_DISPATCH(p, call32, call64) ((p)->prec == 4 ? (call32) : (call64))
 
 namespace {

@@ -177,3 +177,16 @@ def test_out_of_memory_releases_idle_buffers_and_retries():
     assert not eng._pool[1 << 20]                         # the idle buffer went back to the driver
     dx = box.realise_density()                            # the engine is still good
     assert np.isfinite(eng.sum_real(dx, squared=True))
+
+
+def test_stale_runtime_error_of_another_library_is_not_reported():
+    """A failed HIP call elsewhere in the process leaves the runtime's per-thread "last error" set; the launch checks of
+    this library must not mistake it for a failure of their own kernel."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    ptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(1 << 62)) != 0          # out of memory, left unread
+    box = _box(64, 1e3, precision="f32", rng="device", seed=2)
+    dx = box.realise_density()
+    kc, pk, err = box.binned_power_spectrum(delta_x=dx, nbins=10)
+    assert np.isfinite(pk[~np.isnan(pk)]).all()
