@@ -96,8 +96,9 @@ int fb_realise_velocity_device(fb_plan* plan, uint64_t seed, uint64_t realisatio
  * fb_power_spectrum_pending, which fuses the z pass with the first pass of the power spectrum:
  * real_out is written (delta_x is still produced) but never read back.  The y and z passes of every
  * transform run x-plane batch by x-plane batch, so that a batch stays in the Infinity Cache between
- * them (env FB_PLANE_BATCH = planes per batch, 0 = off; FB_PLANE_STREAMS = 2 adds a plan-owned
- * auxiliary stream for alternate batches, joined back into `stream` before the call returns).   */
+ * them (env FB_PLANE_BATCH = planes per batch, 0 = off; FB_PLANE_STREAMS = 1 | 2: with 2, the default
+ * from 1024^3 up, alternate batches run on a plan-owned auxiliary stream that is joined back into
+ * `stream` before the call returns).                                                            */
 int fb_realise_density_begin(fb_plan* plan, uint64_t seed, uint64_t realisation, void* pending_half, void* stream);
 int fb_realise_density_finish(fb_plan* plan, void* pending_half, void* real_out, void* stream);
 
