@@ -162,3 +162,52 @@ def test_rccl_backend_single_rank_collectives():
         assert np.all(np.isfinite(pk[~np.isnan(pk)]))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P", [1, 2])
+def test_slab_path_at_1024(P):
+    """BASELINE config 4's size: the slab-decomposed field and its log-normal P(k) against the single-GPU box (whose
+    y/z passes run plane batch by plane batch on two streams at this size; the slab path keeps whole-slab passes).
+    Compared through device reductions (the cubes are 4.3 GB each)."""
+    from fastbox_amd import CosmoBox, default_cosmo, hostgeom
+    from fastbox_amd.distributed import HipSlabOps, SlabBox, run_virtual
+    N, L, seed, nb = 1024, 2e3, 9, 20
+    ref = CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, precision="f32", rng="device", seed=seed)
+    dx = ref.realise_density()
+    want_sq = ref.engine.sum_real(dx, squared=True)
+    want_sum = ref.engine.sum_real(dx)
+    want = ref.binned_power_spectrum(delta_x=ref.lognormal(dx), nbins=nb)
+    del dx
+    boxes = [SlabBox(default_cosmo, box_scale=L, nsamp=N, precision="f32", seed=seed, rank=r, world=P,
+                     ops_factory=lambda g, PP, rr: HipSlabOps(g, PP, rr, precision="f32", device=0)) for r in range(P)]
+    for b in boxes:
+        b._pk_setup(nb, None)
+
+    def turn(b, recv):
+        b._res = b.ops.new_results(2 * nb + 1)
+        b.delta_x = b.ops.new_real()
+        b._send2 = b._kslab if recv is b._xbuf else b._xbuf
+        b.ops.turnaround(recv, b._half, b.delta_x, b._send2, True, b._res[2 * nb:])
+        return b._send2
+    run_virtual(boxes, lambda b: b._gen_local(), turn)
+    got_sq = sum(float((b.delta_x.double() ** 2).sum()) for b in boxes)
+    got_sum = sum(float(b.delta_x.double().sum()) for b in boxes)
+    assert np.isclose(got_sq, want_sq, rtol=1e-6) and abs(got_sum - want_sum) < 1e-6 * np.sqrt(want_sq * float(N) ** 3)
+    res = run_virtual(boxes, lambda b: b._send2, lambda b, kslab: b._pk_finish(kslab, nb).clone())
+    h = sum(r.cpu().numpy() for r in res)
+    mean = h[2 * nb] / float(N) ** 3
+    pk, err = hostgeom.finish_bins(boxes[0].ops.bin_counts(), h[0:2 * nb:2] / mean ** 2, h[1:2 * nb:2] / mean ** 4,
+                                   boxes[0].boxfactor)
+    m = ~np.isnan(want[1])
+    assert np.array_equal(np.isnan(pk), np.isnan(want[1])) and np.allclose(pk[m], want[1][m], rtol=1e-5, atol=0)
+    # the un-fused pieces (inverse_packed, forward_packed) on fresh ranks: the same realisation again
+    del boxes
+    boxes = [SlabBox(default_cosmo, box_scale=L, nsamp=N, precision="f32", seed=seed, rank=r, world=P,
+                     ops_factory=lambda g, PP, rr: HipSlabOps(g, PP, rr, precision="f32", device=0)) for r in range(P)]
+    for b in boxes:
+        b._pk_setup(nb, None)
+    reals = run_virtual(boxes, lambda b: b._gen_local(), lambda b, recv: b._gen_finish(recv))
+    assert np.isclose(sum(float((r.double() ** 2).sum()) for r in reals), want_sq, rtol=1e-6)
+    res = run_virtual(boxes, lambda b: b._pk_local(b.delta_x, True, nb), lambda b, kslab: b._pk_finish(kslab, nb).clone())
+    h2 = sum(r.cpu().numpy() for r in res)
+    assert np.allclose(h2, h, rtol=2e-6)
