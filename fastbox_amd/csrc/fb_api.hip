@@ -93,6 +93,7 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
     if (!r) r = fb_hip_check(hipMalloc((void**)&p->counts, FB_MAX_BINS * sizeof(unsigned long long)), "hipMalloc");
     if (!r) r = fb_hip_check(hipMalloc((void**)&p->bins, FB_MAX_BINS * sizeof(double)), "hipMalloc");
     if (!r) r = fb_hip_check(hipMalloc((void**)&p->thr, FB_MAX_BINS * sizeof(int)), "hipMalloc");
+    if (!r) r = fb_hip_check(hipMalloc((void**)&p->plane_buf, (size_t)N * N * 2 * precision), "hipMalloc");
     if (r) { fb_plan_destroy(p); return r; }
     p->nbins = 0;
     *plan = p;
@@ -102,11 +103,12 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
 int fb_plan_destroy(fb_plan* p) {
     if (!p) return FB_OK;
     void* ptrs[] = {p->tw, p->axis2, p->ksc, p->kpar, p->zgrid, p->amp_shell, p->amp_sym, p->kperp_tab, p->pca_work, p->bins, p->thr, p->counts,
-                    p->partials, p->scratch, p->bin_partials, p->exp_partials};
+                    p->partials, p->scratch, p->bin_partials, p->exp_partials, p->plane_buf};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     if (p->aux_stream) { (void)hipStreamSynchronize(p->aux_stream); (void)hipStreamDestroy(p->aux_stream); }
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
     delete p;
     return FB_OK;
 }

@@ -10,6 +10,7 @@
 //                   load for the log-normal transform) and c2r (inverse) through the
 //                   packed half-length complex transform.
 #pragma once
+#include <type_traits>
 #include "fb_fft.h"
 #include "fb_field_kernels.h"
 
@@ -62,6 +63,7 @@ template <typename T> struct StridedArgs {
     long long out_outer_stride;
     long long blk_stride;
     int blk_in, blk_out, blk_shift;
+    int packed;              // half spectrum with the k_z = N/2 plane in the imaginary direction of the k_z = 0 plane (ncols = N/2)
 };
 
 // operands of the fused modes (x pass of a half spectrum: line index = k_x,
@@ -72,7 +74,10 @@ template <typename T> struct StridedOp {
     RngKey key;          // GEN
     const int* thr;      // BIN: shell thresholds (cubic boxes only)
     const double* bins;  // BIN: edges, for the shells listed in amb[]
-    double* partial;     // BIN: [2 * nbins][gridDim.x]
+    double* partial;     // BIN: [2 * nbins][partial_stride], this launch fills columns 0 .. gridDim.x - 1
+    long long partial_stride;
+    cx<T>* plane_out;    // BIN of a packed half spectrum: column 0 (= X(k_z=0) + i X(k_z=N/2)) goes to plane_out[k_y][k_x]
+                         // and is binned by k_bin_packed_plane, which has both members of every mirror pair
     int nbins, namb, store;
     int outer0;          // global index of this launch's first outer (k_y) row
     int vel_on, vel_comp;   // GEN: emit i fac delta_k k_c / k^2 (velocity component) instead of delta_k
@@ -125,7 +130,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     TileLayout<T, TZ> lay{tile, c};
 #ifdef FB_STAMPS      // diagnostic build only: phase time stamps of every workgroup (tools/stamps.py)
     long long* stamp = (smode_bins(MODE))
-        ? reinterpret_cast<long long*>(op.partial + (size_t)2 * op.nbins * gridDim.x) + (size_t)blockIdx.x * 8
+        ? reinterpret_cast<long long*>(op.partial + (size_t)2 * op.nbins * op.partial_stride) + (size_t)blockIdx.x * 8
         : reinterpret_cast<long long*>(const_cast<double*>(op.bins)) + (size_t)blockIdx.x * 8;
     const bool stamp_ok = (smode_bins(MODE)) ? (op.partial != nullptr) : (op.bins != nullptr);
 #define FB_STAMP(k) do { if (tid == 0 && stamp_ok) stamp[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -176,58 +181,84 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         const long long ubase = (long long)by * a.outer_stride + bx * TZ;
 
         if constexpr (MODE == SMODE_GEN) {
-            // generator mode k_x = t + j TPL (< N/2) also serves k_x + N/2 (fb_rng.h)
+            // generator: thread pair j holds the modes k_x = t + j TPL (< N/2) and k_x + N/2, which share one
+            // Philox call (fb_rng.h).  `column(kz, ...)` draws and colours this thread's E modes of column k_z.
+            constexpr int H = N >> 1, E2 = E / 2;
             const int ky = by + op.outer0;             // global k_y (slab-decomposed runs own a k_y range)
             const int my = mode_of(ky, N);
-            const int c2 = my * my + col * col;            // col = k_z <= N/2 is its own mode number
-            const T pf = plane_factor<T>(col, N);
-            // spread amplitude table: rows |m_x| = k_x and N/2 - k_x of plane |m_y|, this lane's k_z
-            const long long sym_step = (long long)TPL * ((N >> 1) + 1) * op.g.NZP;
             const int amy = my < 0 ? -my : my;
-            const T* sym0 = op.amp.sym + ((long long)t * ((N >> 1) + 1) + amy) * op.g.NZP + col;
-            const T* sym1 = op.amp.sym + ((long long)((N >> 1) - t) * ((N >> 1) + 1) + amy) * op.g.NZP + col;
-            // velocity mode (single precision): fetch the per-row terms of k^2 and k_c now, so that the
-            // loads are in flight while the random numbers are computed
-            [[maybe_unused]] float vs0[E / 2], vs1[E / 2], vk0[E / 2], vk1[E / 2];
-            if constexpr (sizeof(T) == 4) {
-                if (op.vel_on) {
-                    const int cmp = op.vel_comp;
-                    const int kzc = col < op.g.NZV ? col : 0;                      // padding columns: any valid entry
-                    const float syz = (float)(op.g.axis2[N + ky] + op.g.axis2[2 * N + kzc]);
-                    const int icf = cmp == 1 ? ky : kzc;
-                    const float kcf = (float)(op.g.ksc[cmp * N + icf] * op.vel_fac);
+            const bool rowself = (ky == 0 || ky == H);                          // the row is its own mirror image
+            const bool pk0 = a.packed && bx == 0;      // this tile's column 0 carries the k_z = 0 AND the k_z = N/2 plane
+            const bool has_plane = bx == 0 || (bx * TZ <= H && H < bx * TZ + TZ);
+            // Thread pairs J0 .. J0 + NJ - 1 of column kz.  ACC = false: v[j], v[j + E2] = the coloured modes;
+            // ACC = true: v += i * (those), in the lanes of column 0 only (the shared plane column).  The pass holds 64
+            // VGPRs (two 1024-thread workgroups per CU): the main call forms all E modes in place in v[] with the E/2
+            // Philox calls interleaved, the ACC calls go pair by pair (a second set of E temporaries would spill).
+            auto column = [&](const int kz, auto j0_tag, auto nj_tag, auto acc_tag) {
+                constexpr int J0 = decltype(j0_tag)::value, NJ = decltype(nj_tag)::value;
+                constexpr bool ACC = decltype(acc_tag)::value;
+                const bool plane = (kz == 0) || (kz == H);
+                const bool flip = plane && ky > H;         // drawn as the conjugate of the mirror image's draw
+                const int kyd = flip ? N - ky : ky;
+                // lo(j), hi(j): where pair j's two modes are formed (v[] itself, or temporaries of the ACC call)
+                cx<T> wl[ACC ? NJ : 1], wh[ACC ? NJ : 1];
+                auto lo = [&](int j) -> cx<T>& { if constexpr (ACC) return wl[j - J0]; else return v[j]; };
+                auto hi = [&](int j) -> cx<T>& { if constexpr (ACC) return wh[j - J0]; else return v[j + E2]; };
+                uint32_t X[NJ][4];
 #pragma unroll
-                    for (int j = 0; j < E / 2; ++j) {
-                        const int kx = t + j * TPL, kh = kx + (N >> 1);
-                        vs0[j] = (float)op.g.axis2[kx] + syz;
-                        vs1[j] = (float)op.g.axis2[kh] + syz;
-                        vk0[j] = cmp == 0 ? (float)(op.g.ksc[kx] * op.vel_fac) : kcf;
-                        vk1[j] = cmp == 0 ? (float)(op.g.ksc[kh] * op.vel_fac) : kcf;
-                        if ((cmp == 0 ? kx : icf) == (N >> 1)) vk0[j] = 0.f;       // Nyquist plane of the component
-                        if ((cmp == 0 ? kh : icf) == (N >> 1)) vk1[j] = 0.f;
+                for (int j = J0; j < J0 + NJ; ++j) {
+                    const int g = t + j * TPL;
+                    const int gd = (flip && g > 0) ? H - g : g;
+                    philox_counter(((unsigned long long)gd * N + kyd) * op.g.NZV + kz, 0u, op.key, X[j - J0]);
+                }
+                philox4x32_batch<NJ>(X, op.key.k[0], op.key.k[1]);
+#pragma unroll
+                for (int j = J0; j < J0 + NJ; ++j) {
+                    T a0, a1, b0, b1;
+                    box_muller(X[j - J0][0], X[j - J0][1], a0, a1);
+                    box_muller(X[j - J0][2], X[j - J0][3], b0, b1);
+                    const bool sw = flip && (t + j * TPL) > 0;      // the mirror images of (g, g + N/2) are (N/2 - g) + N/2, N/2 - g
+                    lo(j) = cx<T>{sw ? b0 : a0, sw ? b1 : a1};
+                    hi(j) = cx<T>{sw ? a0 : b0, sw ? a1 : b1};
+                    if (flip) { lo(j).y = -lo(j).y; hi(j).y = -hi(j).y; }
+                }
+                if (has_plane && rowself) {
+                    // rows k_y = 0, N/2 of a plane mirror onto themselves: k_x in (0, N/2) is drawn, k_x + N/2 is the
+                    // conjugate of the draw of N/2 - k_x (a second call), k_x = 0 and N/2 are real
+#pragma unroll
+                    for (int j = J0; j < J0 + NJ; ++j) {
+                        const int g2 = (H - (t + j * TPL)) & (H - 1);
+                        philox_counter(((unsigned long long)g2 * N + ky) * op.g.NZV + kz, 0u, op.key, X[j - J0]);
+                    }
+                    philox4x32_batch<NJ>(X, op.key.k[0], op.key.k[1]);
+#pragma unroll
+                    for (int j = J0; j < J0 + NJ; ++j) {
+                        T c0, c1;
+                        box_muller(X[j - J0][0], X[j - J0][1], c0, c1);
+                        if (plane) {
+                            if (t + j * TPL > 0) hi(j) = cx<T>{c0, -c1};
+                            else {
+                                lo(j) = cx<T>{(T)1.41421356237309504880 * lo(j).x, 0};
+                                hi(j) = cx<T>{(T)1.41421356237309504880 * hi(j).x, 0};
+                            }
+                        }
                     }
                 }
-            }
-            uint32_t ctr[E / 2][4], rnd[E / 2][4];
+                // amplitudes: spread table rows |m_x| = k_x and N/2 - k_x of plane |m_y|, column k_z
+                const long long sym_step = (long long)TPL * (H + 1) * op.g.NZP;
+                const T* sym0 = op.amp.sym + ((long long)t * (H + 1) + amy) * op.g.NZP + kz;
+                const T* sym1 = op.amp.sym + ((long long)(H - t) * (H + 1) + amy) * op.g.NZP + kz;
+                const int c2 = my * my + kz * kz;            // k_z <= N/2 is its own mode number
+                const T pf = (T)0.70710678118654752440;      // E |z|^2 = 1 (fb_rng.h)
 #pragma unroll
-            for (int j = 0; j < E / 2; ++j) {
-                const unsigned long long idx = ((unsigned long long)(t + j * TPL) * N + ky) * op.g.NZV + col;
-                ctr[j][0] = (uint32_t)idx; ctr[j][1] = (uint32_t)(idx >> 32); ctr[j][2] = 0u; ctr[j][3] = 0u;
-            }
-            threefry4x32_20_batch<E / 2>(ctr, op.key.k, rnd);
-#pragma unroll
-            for (int j = 0; j < E / 2; ++j) {
-                const int kx = t + j * TPL;
-                if (valid) {
-                    T a0, a1, b0, b1;
-                    box_muller(rnd[j][0], rnd[j][1], a0, a1);
-                    box_muller(rnd[j][2], rnd[j][3], b0, b1);
+                for (int j = J0; j < J0 + NJ; ++j) {
+                    const int kx = t + j * TPL, kh = kx + H;
                     T A0, A1;
                     if (op.amp.sym) {
                         A0 = sym0[j * sym_step] * pf;
                         A1 = sym1[-j * sym_step] * pf;
                     } else if (op.amp.shell) {
-                        const int mh = kx - (N >> 1);
+                        const int mh = kx - H;
 #ifdef FB_EXPERIMENT_NOAMP
                         A0 = pf; A1 = pf * (T)(mh * mh + c2 > 0 ? 1 : 0);
 #else
@@ -235,31 +266,65 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                         A1 = op.amp.shell[mh * mh + c2] * pf;
 #endif
                     } else {
-                        A0 = op.amp.dense[((long long)kx * op.g.NR + ky) * op.g.NZP + col] * pf;
-                        A1 = op.amp.dense[((long long)(kx + (N >> 1)) * op.g.NR + ky) * op.g.NZP + col] * pf;
+                        A0 = op.amp.dense[((long long)kx * op.g.NR + ky) * op.g.NZP + kz] * pf;
+                        A1 = op.amp.dense[((long long)kh * op.g.NR + ky) * op.g.NZP + kz] * pf;
                     }
-                    v[j] = cx<T>{A0 * a0, A0 * a1};
-                    v[j + E / 2] = cx<T>{A1 * b0, A1 * b1};
-                    if (op.vel_on) {      // wave-uniform: the velocity field of the same realisation
-                        const int kh = kx + (N >> 1), cmp = op.vel_comp;
+                    if (op.vel_on) {      // wave-uniform: the velocity field of the same realisation, i fac delta_k k_c / k^2
+                        const int cmp = op.vel_comp;
+                        const int kzc = kz < op.g.NZV ? kz : 0;                      // padding columns: any valid entry
                         if constexpr (sizeof(T) == 4) {
                             // single precision: k_c fac / k^2, k^2 = 4 pi^2 (s_x + (s_y + s_z)), hardware reciprocal
-                            const float m0 = vs0[j] > 0.f ? vk0[j] * __builtin_amdgcn_rcpf(39.47841760435743f * vs0[j]) : 0.f;
-                            const float m1 = vs1[j] > 0.f ? vk1[j] * __builtin_amdgcn_rcpf(39.47841760435743f * vs1[j]) : 0.f;
-                            v[j] = cx<T>{-v[j].y * m0, v[j].x * m0};
-                            v[j + E / 2] = cx<T>{-v[j + E / 2].y * m1, v[j + E / 2].x * m1};
+                            const float syz = (float)(op.g.axis2[N + ky] + op.g.axis2[2 * N + kzc]);
+                            const int icf = cmp == 1 ? ky : kzc;
+                            const float kcf = (float)(op.g.ksc[cmp * N + icf] * op.vel_fac);
+                            const float s0 = (float)op.g.axis2[kx] + syz, s1 = (float)op.g.axis2[kh] + syz;
+                            float k0 = cmp == 0 ? (float)(op.g.ksc[kx] * op.vel_fac) : kcf;
+                            float k1 = cmp == 0 ? (float)(op.g.ksc[kh] * op.vel_fac) : kcf;
+                            if ((cmp == 0 ? kx : icf) == H) k0 = 0.f;       // Nyquist plane of the component
+                            if ((cmp == 0 ? kh : icf) == H) k1 = 0.f;
+                            const float m0 = s0 > 0.f ? A0 * k0 * __builtin_amdgcn_rcpf(39.47841760435743f * s0) : 0.f;
+                            const float m1 = s1 > 0.f ? A1 * k1 * __builtin_amdgcn_rcpf(39.47841760435743f * s1) : 0.f;
+                            lo(j) = cx<T>{-lo(j).y * m0, lo(j).x * m0};
+                            hi(j) = cx<T>{-hi(j).y * m1, hi(j).x * m1};
                         } else {
-                            const double ay = op.g.axis2[N + ky], az = op.g.axis2[2 * N + col];   // kmag_exact's order
-                            v[j] = velocity_of<T>(op.g, cmp, op.vel_fac, cmp == 0 ? kx : (cmp == 1 ? ky : col),
-                                                  (op.g.axis2[kx] + ay) + az, v[j]);
-                            v[j + E / 2] = velocity_of<T>(op.g, cmp, op.vel_fac, cmp == 0 ? kh : (cmp == 1 ? ky : col),
-                                                          (op.g.axis2[kh] + ay) + az, v[j + E / 2]);
+                            const double ay = op.g.axis2[N + ky], az = op.g.axis2[2 * N + kzc];   // kmag_exact's order
+                            lo(j) = velocity_of<T>(op.g, cmp, op.vel_fac, cmp == 0 ? kx : (cmp == 1 ? ky : kzc),
+                                                   (op.g.axis2[kx] + ay) + az, cscale(lo(j), A0));
+                            hi(j) = velocity_of<T>(op.g, cmp, op.vel_fac, cmp == 0 ? kh : (cmp == 1 ? ky : kzc),
+                                                   (op.g.axis2[kh] + ay) + az, cscale(hi(j), A1));
+                        }
+                    } else {
+                        lo(j) = cscale(lo(j), A0);
+                        hi(j) = cscale(hi(j), A1);
+                    }
+                }
+                if constexpr (ACC) {
+                    if (c == 0) {
+#pragma unroll
+                        for (int j = J0; j < J0 + NJ; ++j) {
+                            v[j] = cx<T>{v[j].x - lo(j).y, v[j].y + lo(j).x};
+                            v[j + E2] = cx<T>{v[j + E2].x - hi(j).y, v[j + E2].y + hi(j).x};
                         }
                     }
-                } else {
-                    v[j] = cx<T>{0, 0};
-                    v[j + E / 2] = cx<T>{0, 0};
                 }
+            };
+            column(col, std::integral_constant<int, 0>{}, std::integral_constant<int, E2>{}, std::false_type{});
+            // packed, tile 0 (wave-uniform): column 0 = (k_z = 0 plane) + i (k_z = N/2 plane), both Hermitian planes
+            if (pk0) {
+                column(H, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::true_type{});
+                if constexpr (E2 > 1) column(H, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::true_type{});
+                if constexpr (E2 > 2) column(H, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::true_type{});
+                if constexpr (E2 > 3) column(H, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::true_type{});
+                if constexpr (E2 > 4) {
+                    column(H, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, std::true_type{});
+                    column(H, std::integral_constant<int, 5>{}, std::integral_constant<int, 1>{}, std::true_type{});
+                    column(H, std::integral_constant<int, 6>{}, std::integral_constant<int, 1>{}, std::true_type{});
+                    column(H, std::integral_constant<int, 7>{}, std::integral_constant<int, 1>{}, std::true_type{});
+                }
+            }
+            if (!valid) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = cx<T>{0, 0};
             }
         } else if constexpr (PERSIST != 1) {
             const cx<T>* src = a.in + ubase + tbase;
@@ -342,6 +407,12 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             // reduction per distinct bin.  tile[] is free: the last exchange ended in a barrier.
             const int nb = op.nbins;
             T* ptile = reinterpret_cast<T*>(smem);                                     // [N][TZ]
+            const bool pk0 = a.packed && bx == 0;          // column 0 of this tile is the shared plane column: not binned here
+            if (pk0 && c == 0) {
+                cx<T>* po = op.plane_out + (long long)(by + op.outer0) * N;
+#pragma unroll
+                for (int e = 0; e < E; ++e) po[t + e * TPL] = v[e];
+            }
 #pragma unroll
             for (int e = 0; e < E; ++e) ptile[(t + e * TPL) * TZ + c] = v[e].x * v[e].x + v[e].y * v[e].y;
             __syncthreads();
@@ -369,7 +440,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 #pragma unroll
                     for (int q = 0; q < E; ++q) {
                         const int n2 = n2row + (kz0 + q) * (kz0 + q);
-                        for (int z = 0; z < op.namb; ++z) mine |= (op.amb[z] == n2) && (kz0 + q < a.ncols);
+                        for (int z = 0; z < op.namb; ++z) mine |= (op.amb[z] == n2) && (kz0 + q < a.ncols) && !(pk0 && kz0 + q == 0);
                     }
                     exact = __any(mine);
                 }
@@ -397,7 +468,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                         for (int q = 0; q < E; ++q) {
                             const int kz = kz0 + q;
                             T p = ptile[off0 + q];
-                            p = (kz >= a.ncols) ? (T)0 : ((kz == 0 || kz == (N >> 1)) ? p : (T)2 * p);   // weight in p
+                            p = (kz >= a.ncols || (pk0 && kz == 0)) ? (T)0 : ((kz == 0 || kz == (N >> 1)) ? p : (T)2 * p);   // weight in p
                             const T p2 = (kz == 0 || kz == (N >> 1)) ? p * p : (T)0.5 * p * p;            // w p^2
                             const bool up = n2row + kz * kz >= edge;
                             s1 += up ? (T)0 : p; s2 += up ? (T)0 : p2;
@@ -422,7 +493,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                 pv[q] = ptile[off0 + q];
                 const int kx = (off0 + q) / TZ, kz = col0 + (off0 + q) % TZ;
                 const int mx = mode_of(kx, N);
-                const bool ok = kz < a.ncols;
+                const bool ok = kz < a.ncols && !(pk0 && kz == 0);
                 const int n2 = mx * mx + my2 + kz * kz;
                 n2v[q] = ok ? n2 : -1;
                 if (ok) { n2lo = n2 < n2lo ? n2 : n2lo; n2hi = n2 > n2hi ? n2 : n2hi; }
@@ -477,7 +548,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         for (int i = tid; i < 2 * nb; i += NT) {          // partial[value][workgroup]
             double sum = 0.0;
             for (int w2 = 0; w2 < NW; ++w2) sum += acc[(size_t)w2 * 2 * nb + i];
-            op.partial[(size_t)i * gridDim.x + blockIdx.x] = sum;
+            op.partial[(size_t)i * op.partial_stride + blockIdx.x] = sum;
         }
         FB_STAMP(7);
     }
@@ -514,6 +585,42 @@ static __global__ __launch_bounds__(256) void k_sum_columns(const double* __rest
     if (threadIdx.x == 0) out[q] = sh[0];
 }
 
+// The shared plane column of a packed half spectrum: G(k_x, k_y) = X0 + i X1 with X0 = X(k_x, k_y, 0) and
+// X1 = X(k_x, k_y, N/2), each Hermitian in (k_x, k_y), so  X0 = (G(k) + conj G(-k)) / 2,  X1 = (G(k) - conj G(-k)) / (2 i).
+// One workgroup per k_y row bins its 2 N modes (weight 1 each, as the k_z = 0, N/2 planes count in a half spectrum)
+// into columns col0 + k_y of partial[value][stride]; a mode's bin as in k_bin_rows' per-mode path (shell thresholds,
+// the exact fp64 |k| for shells within rounding of an edge).  Fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bin_packed_plane(const cx<T>* __restrict__ plane, KGeom g, BinGeom bg,
+                                                           double* __restrict__ partial, long long stride, long long col0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lbins = reinterpret_cast<double*>(smem);           // [nbins]
+    double* acc = lbins + bg.nbins;                            // [4][2 nbins]
+    int* lthr = reinterpret_cast<int*>(acc + 4 * 2 * bg.nbins);
+    const int N = g.N, nb = bg.nbins, tid = threadIdx.x;
+    for (int q = tid; q < nb; q += 256) { lbins[q] = bg.bins[q]; lthr[q] = bg.thr ? bg.thr[q] : 0; }
+    for (int q = tid; q < 8 * nb; q += 256) acc[q] = 0.0;
+    __syncthreads();
+    const int ky = blockIdx.x, kym = (N - ky) & (N - 1);
+    double* row = acc + (size_t)(tid >> 6) * 2 * nb;
+    for (int kx0 = 0; kx0 < N; kx0 += 256) {                   // wave-uniform trip count
+        const int kx = kx0 + tid;
+        const bool have = kx < N;
+        cx<T> G{0, 0}, M{0, 0};
+        if (have) { G = plane[(long long)ky * N + kx]; M = plane[(long long)kym * N + ((N - kx) & (N - 1))]; }
+        const cx<T> x0{(T)0.5 * (G.x + M.x), (T)0.5 * (G.y - M.y)};
+        const cx<T> x1{(T)0.5 * (G.y + M.y), (T)0.5 * (M.x - G.x)};
+        const T p0 = x0.x * x0.x + x0.y * x0.y, p1 = x1.x * x1.x + x1.y * x1.y;
+        const int b0 = have ? bin_of_mode(bg, g, lbins, lthr, kx, ky, 0) : nb;
+        const int b1 = have ? bin_of_mode(bg, g, lbins, lthr, kx, ky, N >> 1) : nb;
+        wave_flush(b0, (double)p0, (double)p0 * (double)p0, have && b0 < nb, row);
+        wave_flush(b1, (double)p1, (double)p1 * (double)p1, have && b1 < nb, row);
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * nb; i += 256)
+        partial[(size_t)i * stride + col0 + blockIdx.x] = (acc[i] + acc[2 * nb + i]) + (acc[4 * nb + i] + acc[6 * nb + i]);
+}
+
 enum { ZMODE_C2C = 0, ZMODE_R2C = 1, ZMODE_C2R = 2, ZMODE_C2R2C = 3 };
 // C2R2C: inverse z pass, write the real field, then (optionally exp() and) forward z pass of the
 // same line from registers: realise_density's last pass fused with the power spectrum's first,
@@ -531,6 +638,7 @@ template <typename T> struct ContigArgs {
     int pre_exp;            // r2c: transform exp(x) instead of x (log-normal fusion)
     double* exp_partial;    // r2c + pre_exp: [gridDim.x] block sums of exp(x)
     void* out2;             // C2R2C: half spectrum out (may alias `in`), pitch/skip as `in`
+    int packed;             // half spectrum rows hold k_z = 0 .. N/2-1, element 0 = X[0] + i X[N/2] (both are real for a real line)
 };
 
 template <int NF> constexpr int contig_lines() {   // lines per workgroup
@@ -570,8 +678,8 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
         for (int e = 0; e < E; ++e) {
             const int k = t + e * TPL;
             cx<T> xk{0, 0}, xn{0, 0};
-            if (valid) { xk = in[k]; xn = in[NF - k]; }
-            if (k == 0) { xk.y = 0; xn.y = 0; }
+            if (valid) { xk = in[k]; xn = in[a.packed ? ((NF - k) & (NF - 1)) : NF - k]; }
+            if (k == 0) { if (a.packed) xn.x = xk.y; xk.y = 0; xn.y = 0; }
             cx<T> s = xk + cconj(xn), d = xk - cconj(xn);
             cx<T> w = cconj(twl[k]);
             cx<T> wd = cmul(w, d);
@@ -614,8 +722,9 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
                 cx<T> zn = cconj(lay.at((NF - k) & (NF - 1)));
                 cx<T> s = zk + zn, d = zk - zn;
                 cx<T> wd = cmul(twl[k], d);
-                out[k] = cx<T>{(T)0.5 * (s.x + wd.y) * sc, (T)0.5 * (s.y - wd.x) * sc};
-                if (k == 0) out[NF] = cx<T>{(zk.x - zk.y) * sc, (T)0};
+                if (k == 0 && a.packed) out[0] = cx<T>{(zk.x + zk.y) * sc, (zk.x - zk.y) * sc};
+                else out[k] = cx<T>{(T)0.5 * (s.x + wd.y) * sc, (T)0.5 * (s.y - wd.x) * sc};
+                if (k == 0 && !a.packed) out[NF] = cx<T>{(zk.x - zk.y) * sc, (T)0};
             }
         }
         if (a.pre_exp) {                       // wave-uniform

@@ -104,26 +104,18 @@ __global__ void k_colour_noise(const T* __restrict__ re, const T* __restrict__ i
 }
 
 // ---- Gaussian field, throughput mode (counter-based RNG, fb_rng.h) ------------------------------
-// Statistically identical to box.py:174-187 without the mirrored draw: a stored mode
-// gets A (g0 + i g1)/sqrt(2); on the self-mirrored planes k_z = 0, N/2 it gets
-// A (g0 + i g1) and the c2r pass's Hermitian projection halves the variance.
-template <typename T>
-__device__ __forceinline__ T plane_factor(int l, int N) {
-    return (l == 0 || l == (N >> 1)) ? (T)1 : (T)0.70710678118654752440;
-}
+// Statistically identical to box.py:174-187 followed by the Hermitian projection that Re ifftn() applies:
+// a stored mode gets A z with E |z|^2 = 1, and the self-mirrored planes k_z = 0, N/2 are drawn Hermitian
+// (fb_rng.h mode_noise), so the half spectrum IS the transform of a real field.
 template <typename T>
 __global__ void k_colour_device(cx<T>* __restrict__ out, AmpSrc<T> amp, KGeom g, RngKey key) {
     const int N = g.N;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, i = blockIdx.z;
     if (l >= g.NZV) return;
-    const int gi = i & ((N >> 1) - 1);
-    const unsigned long long idx = ((unsigned long long)gi * N + j) * g.NZV + l;
-    T a0, a1, b0, b1;
-    mode_noise_pair<T>(idx, 0u, key, a0, a1, b0, b1);
-    const T A = amp_at(amp, g, i, j, l) * plane_factor<T>(l, N);
-    const bool hi = i >= (N >> 1);
-    out[((long long)i * g.NR + j) * g.NZP + l] = cx<T>{A * (hi ? b0 : a0), A * (hi ? b1 : a1)};
+    T re, im;
+    mode_noise<T>(i, j, l, N, g.NZV, key, amp_at(amp, g, i, j, l), re, im);
+    out[((long long)i * g.NR + j) * g.NZP + l] = cx<T>{re, im};
 }
 
 // ---- shell binning of |delta_k|^2 --------------------------------------------------------------
@@ -726,7 +718,7 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         } else if constexpr (E % 4 == 0) {
 #pragma unroll
             for (int q = 0; q < E / 4; ++q)
-                mode_noise_pair<T>((idx0 >> 2) + q, 1u, rkey, nz[4 * q], nz[4 * q + 1], nz[4 * q + 2], nz[4 * q + 3]);
+                stream_normals4<T>((idx0 >> 2) + q, 1u, rkey, nz[4 * q], nz[4 * q + 1], nz[4 * q + 2], nz[4 * q + 3]);
         } else {
 #pragma unroll
             for (int e = 0; e < E; ++e) nz[e] = los_noise_at<T>(idx0 + e, rkey);
@@ -895,7 +887,7 @@ __global__ void k_sky_colour_map(const T* __restrict__ amp2d, const T* __restric
     if (re) { a = re[q]; b = im[q]; }
     else {
         T g0, g1, g2, g3;
-        mode_noise_pair<T>((unsigned long long)(q >> 1), 2u, key, g0, g1, g2, g3);
+        stream_normals4<T>((unsigned long long)(q >> 1), 2u, key, g0, g1, g2, g3);
         a = (q & 1) ? g2 : g0; b = (q & 1) ? g3 : g1;
     }
     const T A = amp2d[q];
@@ -957,7 +949,7 @@ __global__ __launch_bounds__(256) void k_sky_noise_cube(const T* __restrict__ un
     if (q >= n4) return;
     T g[4];
     if (unit) { for (int u = 0; u < 4; ++u) g[u] = unit[4 * q + u]; }
-    else mode_noise_pair<T>((unsigned long long)q, 4u, key, g[0], g[1], g[2], g[3]);
+    else stream_normals4<T>((unsigned long long)q, 4u, key, g[0], g[1], g[2], g[3]);
     const int z0 = (int)((4 * q) % N);
 #pragma unroll
     for (int u = 0; u < 4; ++u) out[4 * q + u] = (T)((double)g[u] * sigma[z0 + u]);

@@ -56,6 +56,8 @@ struct fb_plan {
     double* bin_partials = nullptr;   // fused binning: [workgroups][2*nbins]
     size_t bin_partials_cap = 0;
     long long bin_rows = 0;
+    long long bin_rows_main = 0;      // of which the fused binning pass itself wrote (the rest: k_bin_packed_plane)
+    void* plane_buf = nullptr;        // packed work spectra: the shared plane column after the last forward pass, [N][N] complex
     double* exp_partials = nullptr;   // r2c with exp(): [workgroups]
     size_t exp_partials_cap = 0;
     long long exp_rows = 0;

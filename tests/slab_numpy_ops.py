@@ -49,8 +49,7 @@ class NumpySlabOps(object):
     def x_generate(self, kslab, seed, realisation):
         N, nz = self.N, self.nz
         z = rng.half_spectrum_noise(N, seed, realisation)[:, self.part * self.nloc:(self.part + 1) * self.nloc, :]
-        pf = np.full(nz, np.sqrt(0.5)); pf[0] = pf[-1] = 1.0
-        H = z * self.amp[self._n2()] * pf[None, None, :]
+        H = z * self.amp[self._n2()]
         self._c(kslab)[:, :, :nz] = np.fft.ifft(H, axis=0)
 
     def unpack(self, recv, half_local):

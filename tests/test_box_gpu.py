@@ -398,9 +398,45 @@ def test_device_rng_field_reproduced_on_host(N, L, precision, tol):
     k = bo.k_magnitude(geo)[:, :, :N // 2 + 1]
     pk = np.nan_to_num(standin.pk_fn(standin.cosmology(), 1.0)(k.flatten())).reshape(k.shape)
     amp = np.sqrt(pk * geo["boxfactor"])
-    pf = np.full(N // 2 + 1, np.sqrt(0.5)); pf[0] = pf[-1] = 1.0
-    want = np.fft.irfftn(z * amp * pf[None, None, :], s=(N, N, N), axes=(0, 1, 2))
+    want = np.fft.irfftn(z * amp, s=(N, N, N), axes=(0, 1, 2))
     assert np.max(np.abs(got - want)) < tol * np.std(want)
+
+
+def test_benchmarked_chain_at_512_against_host_model():
+    """The chain bench.py times, at the size the metric is quoted on, against results that do not come from this
+    library: rng='device' realise_density -> lognormal -> binned_power_spectrum(wait=False) at 512^3 runs
+    k_fft_strided<512, GEN> (Philox noise, packed planes), the plane-batched y passes, k_fft_contig<C2R2C> with the
+    fused exp, k_fft_strided<512, BIN> and k_bin_packed_plane.  The field must equal irfftn of the host model's
+    coloured noise (fastbox_amd/rng.py + numpy), its P(k) and the log-normal P(k) must equal the numpy oracle's
+    (oracle/box_oracle.py, the reference's algorithm) on that host field to 1e-5, same NaN mask, same centres."""
+    from fastbox_amd import CosmoBox, default_cosmo, rng
+    N, L, seed = 512, 1e3, 1000
+    box = CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, precision="f32", rng="device",
+                   seed=seed)
+    dx = box.realise_density()                                                        # realisation 0, deferred
+    p_ln = box.binned_power_spectrum(delta_x=box.lognormal(dx), nbins=20, wait=False)   # the benchmarked step
+    p_g = box.binned_power_spectrum(delta_x=dx, nbins=20, wait=False)                   # r2c route on the stored field
+    kc_ln, pk_ln, err_ln = p_ln.result()
+    kc_g, pk_g, err_g = p_g.result()
+    got = np.asarray(dx)
+    geo = bo.box_geometry(L, N)
+    z = rng.half_spectrum_noise(N, seed, 0, np.float32)
+    k = bo.k_magnitude(geo)[:, :, :N // 2 + 1]
+    pk = np.nan_to_num(standin.pk_fn(standin.cosmology(), 1.0)(k.flatten())).reshape(k.shape)
+    z *= np.sqrt(pk * geo["boxfactor"])
+    del k, pk
+    want = np.fft.irfftn(z, s=(N, N, N), axes=(0, 1, 2))
+    del z
+    sd = np.std(want)
+    assert np.max(np.abs(got - want)) < 3e-5 * sd
+    assert abs(np.sum(got * got) / np.sum(want * want) - 1.0) < 1e-6
+    del got
+    for field, (kc, pkv, err) in ((want, (kc_g, pk_g, err_g)), (bo.lognormal(want), (kc_ln, pk_ln, err_ln))):
+        okc, opk, oerr = bo.binned_power_spectrum(geo, np.fft.fftn(field), nbins=20)
+        m = ~np.isnan(opk)
+        assert np.array_equal(np.isnan(pkv), np.isnan(opk)) and np.array_equal(kc, okc)
+        assert np.allclose(pkv[m], opk[m], rtol=1e-5, atol=0)
+        assert np.allclose(err[m], oerr[m], rtol=1e-4, atol=0)
 
 
 @pytest.mark.parametrize("precision", ["f32", "f64"])

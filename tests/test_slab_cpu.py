@@ -27,8 +27,7 @@ def _expected():
     z = rng.half_spectrum_noise(N, SEED, 0)
     k = bo.k_magnitude(geo)[:, :, :N // 2 + 1]
     amp = np.sqrt(np.nan_to_num(pk_fn(k.flatten())).reshape(k.shape) * geo["boxfactor"])
-    pf = np.full(N // 2 + 1, np.sqrt(0.5)); pf[0] = pf[-1] = 1.0
-    dx = np.fft.irfftn(z * amp * pf[None, None, :], s=(N, N, N), axes=(0, 1, 2))
+    dx = np.fft.irfftn(z * amp, s=(N, N, N), axes=(0, 1, 2))
     pk = bo.binned_power_spectrum(geo, np.fft.fftn(dx), nbins=12)
     pkln = bo.binned_power_spectrum(geo, np.fft.fftn(bo.lognormal(dx)), nbins=12)
     return dx, pk, pkln
