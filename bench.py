@@ -5,24 +5,36 @@ configs[1]: "512^3 Gaussian box + log-normal transform + P(k) estimate on 1x MI3
 
 One step = one pass of the hot path through the public API, inputs resident in HBM:
 
-    dx = box.realise_density()                       # Threefry noise, sqrt(P) colouring, c2r 3-D FFT
+    dx = box.realise_density()                       # Philox noise, sqrt(P) colouring, c2r 3-D FFT
     pending = box.binned_power_spectrum(delta_x=box.lognormal(dx), nbins=20, wait=False)
 
 The K pending spectra are resolved (2*20+1 doubles each) inside the timed region, after the
-last step has been queued; fields never leave HBM.  With --gpus N every rank runs
-independent realisations of the same box (Monte-Carlo replicas, no data-path collective;
-"scaling": "weak"); `value` is the whole-job rate.
+last step has been queued; fields never leave HBM.  Independent realisations go round-robin to
+--streams boxes on their own HIP streams (default 2), so that the arithmetic-bound generator /
+binning passes of one realisation run beside the memory-bound passes of another.
 
-Prints ONE JSON line (see README / DESIGN.md for the fields).  `roofline` is for the
-dominant kernel class (the strided x/y FFT passes), timed live with HIP events on the
-launch stream inside the timed region -- every 7th of its launches is bracketed (`launches_timed`
-of `launches`; --kernel-event-stride), since an event pair per launch costs 4 % of the rate
-without changing the average; `cpu_baseline` is the numpy oracle (the reference's algorithm)
-on one core.
+`python bench.py --gpus N` starts N ranks by itself (torch.distributed.run, one per GPU, RCCL) unless it
+is already running under a launcher (WORLD_SIZE set).  Every rank runs independent realisations of the
+same box (Monte-Carlo replicas, no data-path collective; "scaling": "weak"); `value` is the whole-job rate.
+
+Prints ONE JSON line (see README / DESIGN.md for the fields).  Besides the contract's fields:
+  roofline           dominant kernel class (strided y FFT pass), HIP events on the launch stream.  With one stream
+                     the brackets sit inside the timed region (every 7th launch); with several streams kernels of
+                     different boxes share the chip, so the kernel is timed in a separate single-stream pass right
+                     after the timed region ("timed_in" says which)
+  pipeline_roofline  whole step against 8 TB/s, on SURVEY 8(d)'s model bytes and on the bytes actually moved
+  f64                the same step on a precision='f64' plan (the reference computes in complex128)
+  config3            BASELINE configs[2]: gen -> v_z -> redshift space -> wedge filter -> P(k) + filtered field
+  sizes              N = 1: the same step at 256^3, 1024^3, 2048^3 on this GPU
+  strong_scaling     N > 1: ONE box over all ranks (slab-decomposed FFT, RCCL all-to-all) at 1024^3 and 2048^3,
+                     run as child jobs of rank 0 after the replicas leg (a failure there cannot take the line down)
+  cpu_baseline       the numpy oracle (the reference's algorithm) on one host core
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,7 +44,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -41,6 +53,8 @@ def parse():
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--nbins", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed region and its roofline (no f64 / config3 / sizes / strong-scaling legs)")
     ap.add_argument("--cpu-nsamp", type=int, default=0,
                     help="grid of the CPU baseline sample; 0 = the benchmarked size itself up to 512^3 (one step, "
                          "~23 s of one host core), 256^3 scaled by voxel count above that")
@@ -48,20 +62,66 @@ def parse():
                     help="replicas: every rank realises its own boxes (Monte-Carlo throughput, weak scaling; default). "
                          "slab: ONE box of --nsamp^3 spread over the ranks, slab-decomposed FFT with one RCCL "
                          "all-to-all per transform (strong scaling)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="independent realisations are issued round-robin on this many HIP streams (boxes), so that "
-                         "the compute-bound passes of one overlap the HBM-bound passes of the next (+8 %% at 2; "
-                         "default 1 so that per-kernel durations, and the roofline derived from them, are those of "
-                         "kernels running alone)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent realisations are issued round-robin on this many HIP streams (boxes)")
+    ap.add_argument("--plane-batch", type=int, default=None,
+                    help="x-planes per cache-resident batch of the y/z passes (default: the library's size for one box per "
+                         "GPU when --streams 1, N/8 when several boxes share the GPU)")
+    ap.add_argument("--plane-streams", type=int, default=None, help="1 | 2 streams for alternate plane batches")
     ap.add_argument("--kernel-event-stride", type=int, default=7,
-                    help="bracket every K-th launch of the roofline kernel with a HIP event pair, inside the timed region "
-                         "(K coprime to the 8 launches per step, so every position of the step is sampled equally); an "
-                         "event pair costs ~3 us of stream time, so K = 1 (every launch) lowers the measured rate by 4 %% "
-                         "while the average launch duration comes out the same (51.1 vs 51.4 us)")
+                    help="--streams 1: bracket every K-th launch of the roofline kernel with a HIP event pair inside "
+                         "the timed region (an event pair costs ~3 us of stream time)")
     ap.add_argument("--all-kernel-events", action="store_true",
-                    help="bracket every kernel with HIP events (per-kernel breakdown; costs ~4 %% of the rate); "
-                         "by default only the dominant kernel class is bracketed")
-    return ap.parse_args()
+                    help="--streams 1: bracket every kernel with HIP events (per-kernel breakdown; costs ~4 %% of the rate)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+_LAUNCH_ENV = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+               "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+               "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE",
+               "TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCHELASTIC_ERROR_FILE", "OMP_NUM_THREADS")
+
+
+def spawn_ranks(nranks, extra_args, timeout=None):
+    """Run this script as `nranks` fresh processes (torch.distributed.run on 127.0.0.1, one rank per GPU) and return
+    (return code, stdout).  Children are new processes started with subprocess: nothing that has touched the GPU is
+    re-executed.  The launcher's own environment variables are removed so that a nested job forms its own group."""
+    env = {k: v for k, v in os.environ.items() if k not in _LAUNCH_ENV}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(extra_args)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, start_new_session=True, text=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, 15)
+            time.sleep(5)
+            os.killpg(proc.pid, 9)
+        except OSError:
+            pass
+        out, _ = proc.communicate()
+        return -9, out
+    return proc.returncode, out
+
+
+def _last_json(text):
+    for ln in reversed((text or "").strip().splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+    return None
 
 
 def cpu_baseline(nsamp_bench, nsamp_cpu, nbins):
@@ -87,8 +147,158 @@ def cpu_baseline(nsamp_bench, nsamp_cpu, nbins):
                       "(%.1f s, 1 thread), %s" % (nsamp_cpu, dt, how)}
 
 
+def _git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def from_profiles(N, precision):
+    """What the committed rocprofv3 summaries (profiles/, collected off-line by tools/collect_profiles.sh over this
+    command) say about the roofline kernel: PMC traffic per launch (FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md) and the --kernel-trace --stats average duration.  Labelled with the file and the commit it
+    was collected at: these are NOT measured by this run."""
+    out = {"file": None, "head": None, "traffic_bytes_per_launch": None, "rocprof_avg_launch_us": None}
+    try:
+        idx = json.load(open(os.path.join(ROOT, "profiles", "current.json")))
+        out["head"] = idx.get("head")
+        out["file"] = [idx.get("pmc"), idx.get("kernel_stats")]
+        tname = "float" if precision == "f32" else "double"
+        pmc = json.load(open(os.path.join(ROOT, "profiles", idx["pmc"])))
+        key = [k for k in pmc if "k_fft_strided<%s, %d, 0" % (tname, N) in k]
+        if key:
+            c = pmc[key[0]]
+            out["traffic_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024.0
+        import csv
+        with open(os.path.join(ROOT, "profiles", idx["kernel_stats"])) as fh:
+            for row in csv.DictReader(fh):
+                if ("k_fft_strided<%s, %d, 0" % (tname, N)) in row["Name"]:
+                    out["rocprof_avg_launch_us"] = float(row["AverageNs"]) * 1e-3
+    except Exception:
+        pass
+    return out
+
+
+def _make_boxes(args, N, precision, n, rank, local_rank):
+    from fastbox_amd import CosmoBox, default_cosmo
+    from fastbox_amd.device import new_stream
+    boxes = [CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, redshift=0., realise_now=False,
+                      precision=precision, rng="device", seed=1000 * (rank + 1) + i, device=local_rank,
+                      stream=(new_stream(local_rank) if n > 1 else None)) for i in range(max(1, n))]
+    # several boxes share the GPU's 256 MiB Infinity Cache: each keeps a smaller plane batch resident
+    # (512^3 fp32, two boxes: 64 planes = 2 x 70 MB of half spectrum + real planes; measured in profiles/r02_*)
+    sz = 4 if precision == "f32" else 8
+    plane_bytes = (N + 1) * ((N // 2 + 16) // 16 * 16) * 2 * sz + N * N * sz       # half-spectrum plane + real plane
+    share = max(4, int(280e6 / max(1, n) / plane_bytes))
+    pb = args.plane_batch if args.plane_batch is not None else (-1 if n == 1 or share >= N else share)
+    ps = args.plane_streams if args.plane_streams is not None else (0 if n == 1 else 1)
+    for b in boxes:
+        b.engine.set_plane_batching(pb, ps)
+    return boxes
+
+
+def _step_fn(boxes, nbins):
+    counter = [0]
+
+    def step():
+        box = boxes[counter[0] % len(boxes)]
+        counter[0] += 1
+        dx = box.realise_density()
+        return box.binned_power_spectrum(delta_x=box.lognormal(dx), nbins=nbins, wait=False)
+    return step
+
+
+def _warm(step, n):
+    """n untimed steps, queued back to back like the timed ones (the GPU stays busy up to the fence)."""
+    for p in [step() for _ in range(n)]:
+        p.result()
+
+
+def _timed_steps(step, steps, warmup, sync):
+    _warm(step, warmup)
+    sync()
+    t0 = time.perf_counter()
+    pend = [step() for _ in range(steps)]
+    for p in pend:
+        p.result()
+    sync()
+    return time.perf_counter() - t0
+
+
+def quick_rate(args, N, precision, steps, warmup, rank, local_rank, torch):
+    """boxes/s of the benchmarked step at another size / precision (short run, same streams setting)."""
+    boxes = _make_boxes(args, N, precision, args.streams, rank, local_rank)
+    try:
+        dt = _timed_steps(_step_fn(boxes, args.nbins), steps, max(warmup, len(boxes)), torch.cuda.synchronize)
+    finally:
+        for b in boxes:
+            b.engine.close()
+    s = 4 if precision == "f32" else 8
+    sweep = float(N) ** 3 * 2 * s
+    rate = steps / dt
+    return {"nsamp": N, "dtype": precision, "value": rate, "unit": "boxes/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "pipeline_frac_model_bytes": 5.0 * sweep * rate / 1e9 / HBM_PEAK_GBS}
+
+
+def config3_leg(N, local_rank, torch, chains=10):
+    """BASELINE configs[2] on one GPU: gen -> v_z -> redshift-space remap -> k_perp/k_par wedge filter -> P(k) of the
+    filtered field + the filtered field itself, resident in HBM (13.5 sweeps)."""
+    from fastbox_amd import CosmoBox, default_cosmo, Wedge
+    box = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False, precision="f32", rng="device",
+                   seed=5, device=local_rank)
+    eng = box.engine
+    wedge = Wedge(slope=0.3)
+
+    def chain():
+        dx = box.realise_density()
+        vz = box.to_real(box.realise_velocity()[2])
+        ds = box.redshift_space_density(delta_x=dx, velocity_z=vz, sigma_nl=0.0)
+        filt = box.apply_transfer_fn(box.to_k(ds), wedge)
+        pk = box.binned_power_spectrum(delta_x=filt.real, nbins=20, wait=False)
+        filt.ptr                                                # deliver the filtered field as well
+        return pk
+    try:
+        chain().result()
+        chain().result()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pend = [chain() for _ in range(chains)]
+        for p in pend:
+            p.result()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / chains
+        # the remap kernel alone, un-overlapped: HIP events around every launch of its class
+        eng.profile_start(["rsd"], stride=1)
+        pend = [chain() for _ in range(chains)]
+        for p in pend:
+            p.result()
+        prof = eng.profile_stop()
+    finally:
+        eng.close()
+    sweep = float(N) ** 3 * 8
+    rsd_ms, rsd_n = prof["rsd"]
+    rsd_bytes = 1.5 * sweep                                     # R delta 1/2 + R v_z 1/2 + W 1/2 sweeps
+    rsd_gbs = rsd_bytes / (rsd_ms / max(rsd_n, 1) * 1e-3) / 1e9 if rsd_ms > 0 else None
+    return {"workload": "%d^3: realise_density -> realise_velocity[2] -> redshift_space_density -> apply_transfer_fn(Wedge "
+                        "slope 0.3) -> binned_power_spectrum + filtered field" % N,
+            "ms_per_chain": 1e3 * dt, "value": 1.0 / dt, "unit": "chains/s", "chains": chains, "dtype": "f32",
+            "model_sweeps": 13.5, "pipeline_frac_model_bytes": 13.5 * sweep / dt / 1e9 / HBM_PEAK_GBS,
+            "rsd_roofline": {"kernel": "k_rsd_cells", "bound": "hbm", "algorithmic_bytes": rsd_bytes,
+                             "avg_launch_us": 1e3 * rsd_ms / max(rsd_n, 1), "achieved": rsd_gbs, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": rsd_gbs / HBM_PEAK_GBS if rsd_gbs else None}}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand as `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet.
+        rc, out = spawn_ranks(args.gpus, sys.argv[1:])
+        sys.stdout.write(out or "")
+        sys.stdout.flush()
+        sys.exit(rc if rc >= 0 else 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -107,23 +317,14 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     args._reduce_device = "cuda" if backend == "nccl" else "cpu"
-    from fastbox_amd import CosmoBox, default_cosmo
 
     N = args.nsamp
     if args.mode == "slab":
         return slab_main(args, rank, world, local_rank, torch, dist, np)
-    from fastbox_amd.device import new_stream
-    boxes = [CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, redshift=0., realise_now=False,
-                      precision=args.precision, rng="device", seed=1000 * (rank + 1) + i, device=local_rank,
-                      stream=(new_stream() if args.streams > 1 else None)) for i in range(max(1, args.streams))]
+    nstreams = max(1, args.streams)
+    boxes = _make_boxes(args, N, args.precision, nstreams, rank, local_rank)
+    step = _step_fn(boxes, args.nbins)
     eng = boxes[0].engine
-    counter = [0]
-
-    def step():
-        box = boxes[counter[0] % len(boxes)]
-        counter[0] += 1
-        dx = box.realise_density()
-        return box.binned_power_spectrum(delta_x=box.lognormal(dx), nbins=args.nbins, wait=False)
 
     def fence():
         torch.cuda.synchronize()
@@ -131,94 +332,136 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, len(boxes))):
-        step().result()
-    counter[0] = 0
+    # The auxiliary legs run FIRST (rank 0): they are measurements of their own, and they leave the GPU at its
+    # sustained clocks, so that the timed region below is the steady state SURVEY 8(d) defines the metric on
+    # (a cold start reads ~4 % low over a 20-step region: tools/step_timeline.py, profiles/r02_step_timeline.txt).
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        def guarded(name, fn):
+            try:
+                extras[name] = fn()
+            except Exception as e:                     # an extra leg must never take the headline down
+                extras[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        other = "f64" if args.precision == "f32" else "f32"
+        guarded(other, lambda: quick_rate(args, N, other, 10, 2, rank, local_rank, torch))
+        guarded("config3", lambda: config3_leg(N, local_rank, torch))
+        if world == 1:
+            def sizes():
+                out = {}
+                for n2, st in ((256, 100), (1024, 8), (2048, 3)):
+                    if n2 != N:
+                        out[str(n2)] = quick_rate(args, n2, args.precision, st, 2, rank, local_rank, torch)
+                return out
+            guarded("sizes", sizes)
+    _warm(step, max(args.warmup, len(boxes)))
     fence()
+    in_region = nstreams == 1             # event brackets inside the timed region only when kernels run alone
     ev_stride = 1 if args.all_kernel_events else max(1, args.kernel_event_stride)
-    eng.profile_start(None if args.all_kernel_events else ["fft_strided"], stride=ev_stride)
+    if in_region:
+        eng.profile_start(None if args.all_kernel_events else ["fft_strided"], stride=ev_stride)
     t0 = time.perf_counter()
     acc = np.zeros(args.nbins - 1)
     pending = [step() for _ in range(args.steps)]
     for pnd in pending:
         kc, pk, err = pnd.result()
         acc += np.nan_to_num(pk)
-    prof = eng.profile_stop()                    # synchronises the launch stream
-    plain_launches = eng.profile_seen() if ev_stride > 1 else prof["fft_strided"][1]   # all of them, bracketed or not
+    if in_region:
+        prof = eng.profile_stop()                    # synchronises the launch stream
+        plain_launches = eng.profile_seen() if ev_stride > 1 else prof["fft_strided"][1]
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=args._reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
-    if rank == 0:
-        # roofline of the dominant kernel class: strided FFT pass over a half spectrum reads and
-        # writes N*N*(N/2+1) complex values once each (DESIGN.md "Algorithmic bytes")
-        s = 4 if args.precision == "f32" else 8
-        ms, launches = prof["fft_strided"]
-        # a step holds two such passes (inverse and forward y); each is launched once per x-plane batch
-        # (fb_fft_launch.inc yz_passes), so one launch moves its share of the two passes' bytes
-        alg_bytes = 2 * (2.0 * N * N * (N // 2 + 1) * 2 * s) * args.steps / max(plain_launches, 1)
-        achieved = alg_bytes / (ms / max(launches, 1) * 1e-3) / 1e9 if ms > 0 else None
-        total_ms = sum(v[0] for v in prof.values()) * (plain_launches / max(launches, 1) if ev_stride > 1 else 1.)
-        # HBM traffic of the same kernel from the PMC counters: collected off-line in two separate
-        # rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) over this very command and committed under
-        # profiles/; FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md (HBM).
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_fetch_write_summary.json")))
-            key = [k for k in pmc if "k_fft_strided<float, %d, 0" % N in k]
-            if key and args.precision == "f32":
-                c = pmc[key[0]]
-                traffic = (2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024.0
-        except Exception:
-            traffic = None
-        # the committed rocprofv3 --kernel-trace --stats summary of this command, for the cross-check the two
-        # timings owe each other (the event bracket also holds the ~3 us between the event and the kernel's start)
-        rocprof_us = None
-        try:
-            import csv
-            with open(os.path.join(ROOT, "profiles", "r01g_kernel_stats.csv")) as fh:
-                for row in csv.DictReader(fh):
-                    if ("k_fft_strided<%s, %d, 0" % ("float" if s == 4 else "double", N)) in row["Name"]:
-                        rocprof_us = float(row["AverageNs"]) * 1e-3
-        except Exception:
-            rocprof_us = None
-        line = {
-            "metric": "%d^3 box realisations/sec (gen + log-normal + P(k))" % N,
-            "value": world * args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "%d^3 Gaussian box (device Threefry noise, stand-in EH P(k), L=1000 Mpc) + "
-                                   "log-normal transform + binned P(k), nbins=%d" % (N, args.nbins),
-                       "nsamp": N, "parallelism": "replicas x%d" % world, "streams_per_gpu": len(boxes)},
-            "roofline": {"bound": "hbm", "kernel": "k_fft_strided (x/y FFT pass, half spectrum)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
-                         "algorithmic_bytes": alg_bytes,
-                         "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": plain_launches,
-                         "launches_timed": launches, "rocprof_avg_launch_us": rocprof_us},
-            # (sampled brackets: scaled from the timed launches to all of them)
-            "kernel_ms_per_step": {k: round(v[0] / args.steps * (plain_launches / max(v[1], 1) if ev_stride > 1 else 1.), 4)
-                                   for k, v in prof.items() if v[1]},
-            "kernel_ms_total_per_step": round(total_ms / args.steps, 4),
-        }
-        # whole step against the HBM roofline: SURVEY 8(d)'s byte model for this workload is 5.0 sweeps of
-        # N^3 complex values (this implementation moves 4.5: the z passes of realisation and estimate are one)
-        sweep = float(N) ** 3 * 2 * s
-        boxes_per_s = line["value"] / world            # per GPU
-        line["pipeline_roofline"] = {"bound": "hbm", "model_sweeps": 5.0, "moved_sweeps": 4.5,
-                                     "model_bytes_per_box": 5.0 * sweep,
-                                     "achieved": 5.0 * sweep * boxes_per_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": 5.0 * sweep * boxes_per_s / 1e9 / HBM_PEAK_GBS}
-        if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(N, args.cpu_nsamp or (N if N <= 512 else 256), args.nbins)
-        else:
-            line["cpu_baseline"] = None
-        print(json.dumps(line))
-    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank != 0:
+        return
+
+    # ---------------------------------------------------------------- rank 0: the line
+    s = 4 if args.precision == "f32" else 8
+    prof_steps = args.steps
+    timed_in = "timed region (every %d%s launch bracketed)" % (ev_stride, "th" if ev_stride > 1 else "st")
+    if not in_region:
+        # kernels of different boxes overlapped in the timed region: time the roofline kernel on its own, one stream
+        prof_steps = min(max(args.steps, 10), 40)
+        one = _step_fn(boxes[:1], args.nbins)
+        one().result()
+        torch.cuda.synchronize()
+        eng.profile_start(["fft_strided"], stride=1)
+        for p in [one() for _ in range(prof_steps)]:
+            p.result()
+        prof = eng.profile_stop()
+        plain_launches = prof["fft_strided"][1]
+        timed_in = "separate pass of %d steps on ONE stream right after the timed region (in the region itself kernels " \
+                   "of %d boxes share the chip); every launch bracketed" % (prof_steps, nstreams)
+    ms, launches = prof["fft_strided"]
+    # a step holds two strided y passes (inverse and forward), each launched once per x-plane batch (fb_fft_launch.inc
+    # yz_passes): one launch reads and writes its share of N*N*(N/2) complex values (packed work spectrum)
+    ncols = N // 2
+    alg_bytes = 2 * (2.0 * N * N * ncols * 2 * s) * prof_steps / max(plain_launches, 1)
+    achieved = alg_bytes / (ms / max(launches, 1) * 1e-3) / 1e9 if ms > 0 else None
+    fp = from_profiles(N, args.precision)
+    line = {
+        "metric": "%d^3 box realisations/sec (gen + log-normal + P(k))" % N,
+        "value": world * args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": "%d^3 Gaussian box (device Philox4x32-10 noise, stand-in EH P(k), L=1000 Mpc) + "
+                               "log-normal transform + binned P(k), nbins=%d" % (N, args.nbins),
+                   "nsamp": N, "parallelism": "replicas x%d" % world, "streams_per_gpu": len(boxes),
+                   "warmup_steps_run": max(args.warmup, len(boxes))},
+        "roofline": {"bound": "hbm", "kernel": "k_fft_strided (y FFT pass over a plane batch of the half spectrum)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                     "traffic": fp["traffic_bytes_per_launch"], "algorithmic_bytes": alg_bytes,
+                     "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": plain_launches,
+                     "launches_timed": launches, "timed_in": timed_in,
+                     "note": "plane batches are sized to the 256 MiB Infinity Cache, so most of these bytes are served "
+                             "on-die: this is L2 <-> fabric bandwidth; the whole-step figure (pipeline_roofline) is the HBM statement"},
+        "from_profiles": fp,
+    }
+    if in_region:
+        total_ms = sum(v[0] for v in prof.values()) * (plain_launches / max(launches, 1) if ev_stride > 1 else 1.)
+        line["kernel_ms_per_step"] = {k: round(v[0] / args.steps * (plain_launches / max(v[1], 1) if ev_stride > 1 else 1.), 4)
+                                      for k, v in prof.items() if v[1]}
+        line["kernel_ms_total_per_step"] = round(total_ms / args.steps, 4)
+    # whole step against the HBM roofline: SURVEY 8(d)'s byte model for this workload is 5.0 sweeps of N^3 complex
+    # values; this implementation moves 4.5 (the z passes of realisation and estimate are one), of N*N*(N/2) columns
+    sweep = float(N) ** 3 * 2 * s
+    boxes_per_s = line["value"] / world            # per GPU
+    moved = 4.5 * sweep
+    line["pipeline_roofline"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "model_sweeps": 5.0, "model_bytes_per_box": 5.0 * sweep,
+                                 "achieved": 5.0 * sweep * boxes_per_s / 1e9,
+                                 "frac": 5.0 * sweep * boxes_per_s / 1e9 / HBM_PEAK_GBS,
+                                 "moved_sweeps": 4.5, "moved_bytes_per_box": moved,
+                                 "achieved_moved": moved * boxes_per_s / 1e9,
+                                 "frac_moved": moved * boxes_per_s / 1e9 / HBM_PEAK_GBS}
+    for b in boxes:
+        b.engine.close()
+    del boxes
+    line.update(extras)
+    if not args.no_extras and world > 1:
+        # one box over all ranks, as child jobs (the other ranks of this job have left their GPUs by now)
+        out = {}
+        torch.cuda.empty_cache()
+        for n2, st in ((1024, 10), (2048, 5)):
+            try:
+                rc, txt = spawn_ranks(world, ["--mode", "slab", "--nsamp", str(n2), "--steps", str(st), "--warmup", "2",
+                                              "--gpus", str(world), "--precision", args.precision], timeout=420)
+                j = _last_json(txt)
+                out[str(n2)] = j if (rc == 0 and j) else {"error": "slab job rc=%s" % rc}
+            except Exception as e:
+                out[str(n2)] = {"error": "%s: %s" % (type(e).__name__, e)}
+        line["strong_scaling"] = out
+    if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
+        line["cpu_baseline"] = cpu_baseline(N, args.cpu_nsamp or (N if N <= 512 else 256), args.nbins)
+    else:
+        line["cpu_baseline"] = None
+    line["head"] = _git_head()
+    print(json.dumps(line))
 
 
 def slab_main(args, rank, world, local_rank, torch, dist, np):
@@ -230,39 +473,59 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
     box = SlabBox(default_cosmo, box_scale=1e3, nsamp=N, precision=args.precision, seed=1000, rank=rank, world=world,
                   device=local_rank)
 
-    def step():
-        return box.realise_and_power(nbins=args.nbins, lognormal=True)
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(nsteps, wait):
+        """wait=False: Monte-Carlo steps pipelined (exchanges of one realisation behind the passes of its neighbours);
+        wait=True: one realisation at a time, every exchange exposed."""
+        fence()
+        t0 = time.perf_counter()
+        if wait:
+            for _ in range(nsteps):
+                box.realise_and_power(nbins=args.nbins, lognormal=True)
+        else:
+            tickets = [box.realise_and_power(nbins=args.nbins, lognormal=True, wait=False) for _ in range(nsteps)]
+            for tk in tickets:
+                tk.result()
+        fence()
+        d = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([d], dtype=torch.float64, device=args._reduce_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return d
+
     for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        kc, pk, err = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=args._reduce_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        box.realise_and_power(nbins=args.nbins, lognormal=True)
+    timed(3, False)
+    dt = timed(args.steps, False)
+    dt_sync = timed(max(2, args.steps // 2), True) / max(2, args.steps // 2) if world > 1 else None
     if rank == 0:
         s = 4 if args.precision == "f32" else 8
+        sweep = float(N) ** 3 * 2 * s
+        a2a = (N // world) ** 2 * ((N // 2 + 16) // 16 * 16) * 2 * s
+        timing = None if dt_sync is None else {
+            "ms_per_step_one_realisation_at_a_time": 1e3 * dt_sync,
+            "ms_per_step_pipelined": 1e3 * dt / args.steps,
+            "all_to_alls_per_step": 2, "bytes_sent_per_rank_per_all_to_all": a2a * (world - 1),
+            "note": "pipelined = up to three realisations in flight, both all-to-alls asynchronous on the RCCL stream "
+                    "behind other realisations' passes; the difference to the first figure is the exchange time that "
+                    "overlap hides"}
         print(json.dumps({
             "metric": "%d^3 box realisations/sec (gen + log-normal + P(k)), one box over all GPUs" % N,
             "value": args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "%d^3 Gaussian box + log-normal + binned P(k), slab-decomposed FFT, one all-to-all "
-                                   "per transform, P(k) synchronised every step" % N, "nsamp": N,
+                                   "per transform" % N, "nsamp": N,
                        "parallelism": "slab x%d" % world,
                        "all_to_all_bytes_per_rank_pair": (N // world) ** 2 * ((N // 2 + 16) // 16 * 16) * 2 * s},
-            "roofline": None, "cpu_baseline": None}))
+            "pipeline_frac_model_bytes": 5.0 * sweep * (args.steps / dt) / 1e9 / (HBM_PEAK_GBS * world),
+            "exchange": timing, "roofline": None, "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
 

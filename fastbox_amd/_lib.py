@@ -87,6 +87,7 @@ SIGNATURES = {
     "fb_slab_x_generate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_u64, c_u64, c_void_p]),
     "fb_slab_x_bin": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fb_set_tuning": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "fb_set_plane_batching": (c_int, [c_void_p, c_int, c_int]),
     "fb_debug_strided_pass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fb_debug_read_stamps": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), c_i64]),
     "fb_profile_select": (c_int, [c_void_p, ctypes.c_uint]),
@@ -102,6 +103,7 @@ SIGNATURES = {
     "fb_stream_destroy": (c_int, [c_void_p]),
     "fb_stream_sync": (c_int, [c_void_p]),
     "fb_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "fb_device_set": (c_int, [c_int]),
 }
 
 FB_FILT_TABLE, FB_FILT_BEAM_HIGHPASS, FB_FILT_WEDGE, FB_FILT_TOPHAT = 0, 1, 2, 3

@@ -10,10 +10,15 @@ image, so the values it would return are *parity unpinned* (SURVEY.md par. 8c).
 This module supplies the same function names with a closed-form flat-LCDM
 model so that ``CosmoBox(default_cosmo)`` works offline:
 
-  * linear P(k): Eisenstein & Hu (1998) zero-baryon ("no-wiggle") transfer
-    function, primordial tilt ``n_s``, normalised to ``sigma8`` with an
-    8 Mpc/h top-hat;
-  * ``nonlin_matter_power`` == linear (no halofit correction yet);
+  * linear P(k): the full Eisenstein & Hu (1998) fitting formula (CDM + baryon
+    transfer functions with the acoustic oscillations and Silk damping, their
+    eqs. 2-24) for ``transfer_function='eisenstein_hu'`` -- what pyccl means by
+    that name -- or their zero-baryon form (eqs. 26-31) for
+    ``'eisenstein_hu_nowiggles'``; primordial tilt ``n_s``, normalised to
+    ``sigma8`` with an 8 Mpc/h top-hat;
+  * ``nonlin_matter_power``: halofit (Smith et al. 2003 with the Takahashi et
+    al. 2012 coefficients, flat LCDM, w = -1) on that linear spectrum -- pyccl's
+    default ``matter_power_spectrum='halofit'``;
   * E(a), D(a), f(a), chi(a) for flat LCDM without radiation.
 
 If the real ``pyccl`` is importable, ``fastbox_amd.box`` uses it instead.
@@ -64,8 +69,55 @@ class Cosmology(object):
         C0 = 14.2 + 731.0 / (1.0 + 62.5 * q)
         return L0 / (L0 + C0 * q * q)
 
+    def _transfer_wiggles(self, k):
+        """EH98 eqs. 2-24 (CDM + baryons, no neutrinos); ``k`` in 1/Mpc."""
+        p = self._p
+        h = p['h']
+        om, ob = p['Omega_m'], p['Omega_b']
+        omh2, obh2 = om * h * h, ob * h * h
+        fb = ob / om
+        fc = 1.0 - fb
+        th2 = (p['T_CMB'] / 2.7) ** 2
+        zeq = 2.50e4 * omh2 / th2 ** 2
+        keq = 7.46e-2 * omh2 / th2
+        b1 = 0.313 * omh2 ** -0.419 * (1.0 + 0.607 * omh2 ** 0.674)
+        b2 = 0.238 * omh2 ** 0.223
+        zd = 1291.0 * omh2 ** 0.251 / (1.0 + 0.659 * omh2 ** 0.828) * (1.0 + b1 * obh2 ** b2)
+        Req = 31.5 * obh2 / th2 ** 2 * (1e3 / zeq)
+        Rd = 31.5 * obh2 / th2 ** 2 * (1e3 / zd)
+        s = 2.0 / (3.0 * keq) * np.sqrt(6.0 / Req) * np.log((np.sqrt(1.0 + Rd) + np.sqrt(Rd + Req)) / (1.0 + np.sqrt(Req)))
+        ksilk = 1.6 * obh2 ** 0.52 * omh2 ** 0.73 * (1.0 + (10.4 * omh2) ** -0.95)
+        q = k / (13.41 * keq)
+        a1 = (46.9 * omh2) ** 0.670 * (1.0 + (32.1 * omh2) ** -0.532)
+        a2 = (12.0 * omh2) ** 0.424 * (1.0 + (45.0 * omh2) ** -0.582)
+        alpha_c = a1 ** -fb * a2 ** -(fb ** 3)
+        bb1 = 0.944 / (1.0 + (458.0 * omh2) ** -0.708)
+        bb2 = (0.395 * omh2) ** -0.0266
+        beta_c = 1.0 / (1.0 + bb1 * (fc ** bb2 - 1.0))
+
+        def T0(ac, bc):
+            L = np.log(np.e + 1.8 * bc * q)
+            C = 14.2 / ac + 386.0 / (1.0 + 69.9 * q ** 1.08)
+            return L / (L + C * q * q)
+        ks = k * s
+        f = 1.0 / (1.0 + (ks / 5.4) ** 4)
+        Tc = f * T0(1.0, beta_c) + (1.0 - f) * T0(alpha_c, beta_c)
+        y = (1.0 + zeq) / (1.0 + zd)
+        G = y * (-6.0 * np.sqrt(1.0 + y) + (2.0 + 3.0 * y) * np.log((np.sqrt(1.0 + y) + 1.0) / (np.sqrt(1.0 + y) - 1.0)))
+        alpha_b = 2.07 * keq * s * (1.0 + Rd) ** -0.75 * G
+        beta_b = 0.5 + fb + (3.0 - 2.0 * fb) * np.sqrt((17.2 * omh2) ** 2 + 1.0)
+        beta_node = 8.41 * omh2 ** 0.435
+        st = s / (1.0 + (beta_node / ks) ** 3) ** (1.0 / 3.0)
+        Tb = (T0(1.0, 1.0) / (1.0 + (ks / 5.2) ** 2)
+              + alpha_b / (1.0 + (beta_b / ks) ** 3) * np.exp(-(k / ksilk) ** 1.4)) * np.sinc(k * st / np.pi)
+        return fb * Tb + fc * Tc
+
     def _pk_shape(self, k):
-        return k ** self._p['n_s'] * self._transfer_nowiggle(k) ** 2
+        if self._p['transfer_function'] == 'eisenstein_hu_nowiggles':
+            T = self._transfer_nowiggle(k)
+        else:
+            T = self._transfer_wiggles(k)
+        return k ** self._p['n_s'] * T ** 2
 
     def _amplitude(self):
         if self._norm is None:
@@ -137,6 +189,68 @@ def linear_matter_power(cosmo, k, a):
     return out
 
 
+def _halofit_params(cosmo, a):
+    """(k_sigma, n_eff, C) of the linear spectrum at scale factor ``a`` (Smith et al. 2003 eqs. C6-C8 with the
+    Gaussian-filtered variance sigma^2(R) = int dlnk Delta_L^2(k) exp(-k^2 R^2)), or None if sigma(R) never
+    reaches 1 on the scales resolved here (the field is linear)."""
+    key = ("halofit", float(a))
+    cache = cosmo.__dict__.setdefault("_cache", {})
+    if key in cache:
+        return cache[key]
+    lk = np.linspace(np.log(1e-5), np.log(3e3), 6001)
+    k = np.exp(lk)
+    D = growth_factor(cosmo, a)
+    d2 = k ** 3 * cosmo._amplitude() * cosmo._pk_shape(k) * D * D / (2.0 * np.pi ** 2)
+
+    def sig2(R):
+        return _TRAPZ(d2 * np.exp(-(k * R) ** 2), lk)
+    lo, hi = np.log(1e-4), np.log(1e2)         # ln R, Mpc
+    if sig2(np.exp(lo)) < 1.0:
+        cache[key] = None
+        return None
+    for _ in range(80):
+        mid = 0.5 * (lo + hi)
+        if sig2(np.exp(mid)) > 1.0:
+            lo = mid
+        else:
+            hi = mid
+    R = np.exp(0.5 * (lo + hi))
+    y2 = (k * R) ** 2
+    e = np.exp(-y2)
+    S = _TRAPZ(d2 * e, lk)
+    S1 = -2.0 * _TRAPZ(d2 * y2 * e, lk)                     # dS/dlnR
+    S2 = _TRAPZ(d2 * (4.0 * y2 * y2 - 4.0 * y2) * e, lk)    # d2S/dlnR2
+    neff = -3.0 - S1 / S
+    C = (S1 / S) ** 2 - S2 / S
+    cache[key] = (1.0 / R, neff, C)
+    return cache[key]
+
+
 def nonlin_matter_power(cosmo, k, a):
-    """Stand-in: identical to the linear spectrum (no halofit)."""
-    return linear_matter_power(cosmo, k, a)
+    """Non-linear P(k, a): halofit (Smith et al. 2003; coefficients of Takahashi et al. 2012, their eqs. A6-A13,
+    flat LCDM with w = -1) applied to ``linear_matter_power``.  NaN at k = 0 like the linear spectrum."""
+    k = np.asarray(k, dtype=np.float64)
+    plin = linear_matter_power(cosmo, k, a)
+    prm = _halofit_params(cosmo, a)
+    if prm is None:
+        return plin
+    ksig, n, C = prm
+    om_a = cosmo['Omega_m'] * float(a) ** -3 / float(_E(cosmo, a)) ** 2
+    an = 10.0 ** (1.5222 + 2.8553 * n + 2.3706 * n ** 2 + 0.9903 * n ** 3 + 0.2250 * n ** 4 - 0.6038 * C)
+    bn = 10.0 ** (-0.5642 + 0.5864 * n + 0.5716 * n ** 2 - 1.5474 * C)
+    cn = 10.0 ** (0.3698 + 2.0404 * n + 0.8161 * n ** 2 + 0.5869 * C)
+    gam = 0.1971 - 0.0843 * n + 0.8460 * C
+    alp = abs(6.0835 + 1.3373 * n - 0.1959 * n ** 2 - 5.5274 * C)
+    bet = 2.0379 - 0.7354 * n + 0.3157 * n ** 2 + 1.2490 * n ** 3 + 0.3980 * n ** 4 - 0.1682 * C
+    nun = 10.0 ** (5.2105 + 3.6902 * n)
+    f1, f2, f3 = om_a ** -0.0307, om_a ** -0.0585, om_a ** 0.0743
+    out = np.full(k.shape, np.nan)
+    good = k > 0.0
+    kk = k[good]
+    y = kk / ksig
+    dl = kk ** 3 * plin[good] / (2.0 * np.pi ** 2)
+    dq = dl * ((1.0 + dl) ** bet / (1.0 + alp * dl)) * np.exp(-(y / 4.0 + y * y / 8.0))
+    dh = an * y ** (3.0 * f1) / (1.0 + bn * y ** f2 + (cn * f3 * y) ** (3.0 - gam))
+    dh = dh / (1.0 + nun / (y * y))
+    out[good] = (dq + dh) * (2.0 * np.pi ** 2) / kk ** 3
+    return out

@@ -23,6 +23,11 @@ int fb_hip_check(hipError_t e, const char* what) {
 // HIP runtime may have left in this thread, so that the launch checks below report this call's errors only)
 #define FB_REQUIRE(cond, msg) do { (void)hipGetLastError(); if (!(cond)) { fb_set_error(msg); return FB_ERR_INVALID; } } while (0)
 #define FB_DISPATCH(p, call32, call64) ((p)->prec == 4 ? (call32) : (call64))
+// A plan belongs to one device.  Every entry point that takes a plan makes that device current first (allocations,
+// NULL-stream launches and the plan's own auxiliary stream / events all follow the current device), so plans on
+// different GPUs can be used from one thread in any order.
+#define FB_USE_DEVICE(p) do { int _dev = -1; if (hipGetDevice(&_dev) != hipSuccess || _dev != (p)->device) \
+                                  FB_HIP(hipSetDevice((p)->device)); } while (0)
 
 namespace {
 template <typename T> int upload(T** dst, const T* src, size_t n) {
@@ -51,6 +56,12 @@ const char* fb_last_error(void) { return g_last_error.c_str(); }
 int fb_device_count(int* count) {
     FB_REQUIRE(count, "null pointer");
     FB_HIP(hipGetDeviceCount(count));
+    return FB_OK;
+}
+
+int fb_device_set(int device) {
+    (void)hipGetLastError();
+    FB_HIP(hipSetDevice(device));
     return FB_OK;
 }
 
@@ -102,6 +113,7 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
 
 int fb_plan_destroy(fb_plan* p) {
     if (!p) return FB_OK;
+    (void)hipSetDevice(p->device);
     void* ptrs[] = {p->tw, p->axis2, p->ksc, p->kpar, p->zgrid, p->amp_shell, p->amp_sym, p->kperp_tab, p->pca_work, p->bins, p->thr, p->counts,
                     p->partials, p->scratch, p->bin_partials, p->exp_partials, p->plane_buf};
     for (void* q : ptrs) if (q) (void)hipFree(q);
@@ -121,45 +133,61 @@ int64_t fb_full_bytes(const fb_plan* p) { return p ? (int64_t)p->N * p->N * p->N
 
 int fb_fft_c2c(fb_plan* p, void* d, int direction, double scale, void* stream) {
     FB_REQUIRE(p && d, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(direction == 1 || direction == -1, "direction must be +1 or -1");
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_fft_c2c_f32(p, d, direction, scale, s), fbi_fft_c2c_f64(p, d, direction, scale, s));
 }
 int fb_fft_r2c(fb_plan* p, const void* in, void* out, int pre_exp, void* stream) {
     FB_REQUIRE(p && in && out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_fft_r2c_f32(p, in, out, pre_exp, s), fbi_fft_r2c_f64(p, in, out, pre_exp, s));
 }
 int fb_fft_c2r(fb_plan* p, void* half, void* out, double scale, void* stream) {
     FB_REQUIRE(p && half && out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_fft_c2r_f32(p, half, out, scale, s), fbi_fft_c2r_f64(p, half, out, scale, s));
 }
 
+// The plan's lookup tables (amplitudes, bin edges / thresholds) are read by kernels on whatever stream the caller
+// launches them on, so a table is only rewritten once everything queued on the device has finished: table changes are
+// rare (a new P(k), a new bin set), a device-wide wait is the one form that covers every caller stream.
+#define FB_QUIESCE() FB_HIP(hipDeviceSynchronize())
+
 int fb_set_amplitude_shells(fb_plan* p, const double* amp, int64_t nshell) {
     FB_REQUIRE(p && amp, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(p->cubic, "shell amplitudes need a cubic box (use fb_set_amplitude_dense)");
     const int64_t need = 3LL * (p->N / 2) * (p->N / 2) + 1;
     FB_REQUIRE(nshell == need, "nshell must be 3 (N/2)^2 + 1");
+    FB_QUIESCE();
     p->amp_dense = nullptr;
     return FB_DISPATCH(p, fbi_set_amp_shells_f32(p, amp, nshell), fbi_set_amp_shells_f64(p, amp, nshell));
 }
 int fb_set_amplitude_sym(fb_plan* p, const double* amp, int64_t n) {
     FB_REQUIRE(p && amp, "null pointer");
+    FB_USE_DEVICE(p);
+    FB_QUIESCE();
     return FB_DISPATCH(p, fbi_set_amp_sym_f32(p, amp, n), fbi_set_amp_sym_f64(p, amp, n));
 }
 int fb_set_amplitude_dense(fb_plan* p, const void* amp_dev) {
     FB_REQUIRE(p && amp_dev, "null pointer");
+    FB_USE_DEVICE(p);
+    FB_QUIESCE();
     p->amp_dense = amp_dev;
     return FB_OK;
 }
 int fb_colour_noise(fb_plan* p, const void* re, const void* im, void* out, void* stream) {
     FB_REQUIRE(p && re && im && out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_colour_noise_f32(p, re, im, out, s), fbi_colour_noise_f64(p, re, im, out, s));
 }
 int fb_colour_device(fb_plan* p, uint64_t seed, uint64_t realisation, void* out, void* stream) {
     FB_REQUIRE(p && out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_colour_device_f32(p, seed, realisation, out, s),
                        fbi_colour_device_f64(p, seed, realisation, out, s));
@@ -167,10 +195,12 @@ int fb_colour_device(fb_plan* p, uint64_t seed, uint64_t realisation, void* out,
 
 int fb_set_bins(fb_plan* p, const double* edges, int nbins, const int32_t* thr, const int32_t* amb, int namb) {
     FB_REQUIRE(p && edges, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(nbins >= 1 && nbins <= FB_MAX_BINS, "nbins must be in 1..256");
     FB_REQUIRE(namb >= 0 && namb <= 8, "at most 8 ambiguous shells");
     for (int q = 1; q < nbins; ++q) FB_REQUIRE(edges[q] >= edges[q - 1], "bin edges must be ascending");
     FB_REQUIRE(!thr || p->cubic, "shell thresholds need a cubic box");
+    FB_QUIESCE();
     FB_HIP(hipMemcpy(p->bins, edges, (size_t)nbins * sizeof(double), hipMemcpyHostToDevice));
     p->nbins = nbins;
     static_assert(sizeof(int) == sizeof(int32_t), "int");
@@ -181,7 +211,10 @@ int fb_set_bins(fb_plan* p, const double* edges, int nbins, const int32_t* thr, 
         p->namb = namb;
         for (int q = 0; q < namb; ++q) p->amb[q] = amb[q];
     }
-    return fbi_bin_count(p, 0);
+    int r = fbi_bin_count(p, 0);
+    if (r) return r;
+    FB_HIP(hipStreamSynchronize(0));      // caller streams may be non-blocking: the counts / tables are complete on return
+    return FB_OK;
 }
 
 namespace {
@@ -211,12 +244,14 @@ int fb_bin_power(fb_plan* p, const void* spec, int layout, double* count, double
 int fb_bin_power_filtered(fb_plan* p, const void* spec, int layout, int kind, const double* params,
                           const void* table_dev, double* count, double* sum, double* sumsq, void* stream) {
     FB_REQUIRE(kind >= 0, "unknown filter kind");
+    FB_USE_DEVICE(p);
     return bin_power_common(p, spec, layout, kind, params, table_dev, count, sum, sumsq, stream);
 }
 
 int fb_apply_filter(fb_plan* p, const void* in, void* out, int layout, int kind, const double* params,
                     const void* table_dev, void* stream) {
     FB_REQUIRE(p && in && out, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(layout == 0 || layout == 1, "layout must be 0 (full) or 1 (half)");
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_apply_filter_f32(p, in, out, layout, kind, params, table_dev, s),
@@ -224,6 +259,7 @@ int fb_apply_filter(fb_plan* p, const void* in, void* out, int layout, int kind,
 }
 int fb_velocity_k(fb_plan* p, const void* dk, void* out, int layout, int component, double fac, void* stream) {
     FB_REQUIRE(p && dk && out, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(layout == 0 || layout == 1, "layout must be 0 (full) or 1 (half)");
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_velocity_f32(p, dk, out, layout, component, fac, s),
@@ -231,18 +267,21 @@ int fb_velocity_k(fb_plan* p, const void* dk, void* out, int layout, int compone
 }
 int fb_potential_k(fb_plan* p, const void* dk, void* out, int layout, void* stream) {
     FB_REQUIRE(p && dk && out, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(layout == 0 || layout == 1, "layout must be 0 (full) or 1 (half)");
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_potential_f32(p, dk, out, layout, s), fbi_potential_f64(p, dk, out, layout, s));
 }
 int fb_lognormal(fb_plan* p, const void* in, void* out, double* mean_out, void* stream) {
     FB_REQUIRE(p && in && out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_lognormal_f32(p, in, out, mean_out, s), fbi_lognormal_f64(p, in, out, mean_out, s));
 }
 int fb_redshift_space(fb_plan* p, const void* delta, const void* vz, const void* noise, void* out, double Hz,
                       double sigma_nl, uint64_t seed, void* stream) {
     FB_REQUIRE(p && delta && vz && out, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(Hz > 0, "Hz must be positive");
     FB_REQUIRE(out != delta && out != vz, "redshift_space is out of place");
     hipStream_t s = (hipStream_t)stream;
@@ -251,21 +290,25 @@ int fb_redshift_space(fb_plan* p, const void* delta, const void* vz, const void*
 }
 int fb_sum_real(fb_plan* p, const void* x, int squared, double* out, void* stream) {
     FB_REQUIRE(p && x && out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_sum_real_f32(p, x, squared, out, s), fbi_sum_real_f64(p, x, squared, out, s));
 }
 int fb_sumsq_half(fb_plan* p, const void* h, double* out, void* stream) {
     FB_REQUIRE(p && h && out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_sumsq_half_f32(p, h, out, s), fbi_sumsq_half_f64(p, h, out, s));
 }
 int fb_expand_half(fb_plan* p, const void* half, void* full, void* stream) {
     FB_REQUIRE(p && half && full, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_expand_half_f32(p, half, full, s), fbi_expand_half_f64(p, half, full, s));
 }
 int fb_crop_full(fb_plan* p, const void* full, void* half, void* stream) {
     FB_REQUIRE(p && half && full, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_crop_full_f32(p, full, half, s), fbi_crop_full_f64(p, full, half, s));
 }
@@ -273,6 +316,7 @@ int fb_crop_full(fb_plan* p, const void* full, void* half, void* stream) {
 int fb_realise_density_device(fb_plan* p, uint64_t seed, uint64_t realisation, void* work_half, void* real_out,
                               void* stream) {
     FB_REQUIRE(p && work_half && real_out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     const double scale = 1.0 / ((double)p->N * p->N * p->N);
     return FB_DISPATCH(p, fbi_realise_fused_f32(p, seed, realisation, work_half, real_out, scale, s),
@@ -281,6 +325,7 @@ int fb_realise_density_device(fb_plan* p, uint64_t seed, uint64_t realisation, v
 int fb_realise_velocity_device(fb_plan* p, uint64_t seed, uint64_t realisation, int comp, double fac,
                                void* work_half, void* real_out, void* stream) {
     FB_REQUIRE(p && work_half && real_out, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(comp >= 0 && comp <= 2, "component must be 0, 1 or 2");
     FB_REQUIRE(p->N % 2 == 0, "velocity needs an even grid size");
     hipStream_t s = (hipStream_t)stream;
@@ -290,12 +335,14 @@ int fb_realise_velocity_device(fb_plan* p, uint64_t seed, uint64_t realisation, 
 }
 int fb_realise_density_begin(fb_plan* p, uint64_t seed, uint64_t realisation, void* pending_half, void* stream) {
     FB_REQUIRE(p && pending_half, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_realise_begin_f32(p, seed, realisation, pending_half, s),
                        fbi_realise_begin_f64(p, seed, realisation, pending_half, s));
 }
 int fb_realise_density_finish(fb_plan* p, void* pending_half, void* real_out, void* stream) {
     FB_REQUIRE(p && pending_half && real_out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     const double scale = 1.0 / ((double)p->N * p->N * p->N);
     return FB_DISPATCH(p, fbi_realise_finish_f32(p, pending_half, real_out, scale, s),
@@ -304,6 +351,7 @@ int fb_realise_density_finish(fb_plan* p, void* pending_half, void* real_out, vo
 int fb_power_spectrum_filtered(fb_plan* p, const void* real_in, void* filtered_half, int kind, const double* params,
                                const void* table_dev, void* results_dev, void* stream) {
     FB_REQUIRE(p && real_in && filtered_half && results_dev, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_power_filtered_f32(p, real_in, filtered_half, kind, params, table_dev, (double*)results_dev, s),
                        fbi_power_filtered_f64(p, real_in, filtered_half, kind, params, table_dev, (double*)results_dev, s));
@@ -311,6 +359,7 @@ int fb_power_spectrum_filtered(fb_plan* p, const void* real_in, void* filtered_h
 int fb_power_spectrum_pending(fb_plan* p, void* pending_half, void* real_out, int pre_exp, double* results_dev,
                               void* stream) {
     FB_REQUIRE(p && pending_half && real_out && results_dev, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     const double scale = 1.0 / ((double)p->N * p->N * p->N);
     return FB_DISPATCH(p, fbi_power_from_pending_f32(p, pending_half, real_out, scale, pre_exp, results_dev, s),
@@ -319,12 +368,14 @@ int fb_power_spectrum_pending(fb_plan* p, void* pending_half, void* real_out, in
 int fb_power_spectrum_device(fb_plan* p, const void* real_in, void* work_half, int pre_exp, int keep_spectrum,
                              double* results_dev, void* stream) {
     FB_REQUIRE(p && real_in && work_half && results_dev, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_power_fused_f32(p, real_in, work_half, pre_exp, keep_spectrum, results_dev, s),
                        fbi_power_fused_f64(p, real_in, work_half, pre_exp, keep_spectrum, results_dev, s));
 }
 int fb_bin_counts(fb_plan* p, double* count) {
     FB_REQUIRE(p && count, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(p->nbins > 0, "bin edges not set");
     for (int q = 0; q < p->nbins; ++q) count[q] = p->counts_host[q];
     return FB_OK;
@@ -332,11 +383,13 @@ int fb_bin_counts(fb_plan* p, double* count) {
 
 int fb_real_axpby(fb_plan* p, const void* x, const void* y, void* out, double a, double b, double c, void* stream) {
     FB_REQUIRE(p && x && out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_real_axpby_f32(p, x, y, out, a, b, c, 0, s), fbi_real_axpby_f64(p, x, y, out, a, b, c, 0, s));
 }
 int fb_real_multiply(fb_plan* p, const void* x, const void* y, void* out, void* stream) {
     FB_REQUIRE(p && x && y && out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_real_axpby_f32(p, x, y, out, 0, 0, 0, 1, s), fbi_real_axpby_f64(p, x, y, out, 0, 0, 0, 1, s));
 }
@@ -344,6 +397,7 @@ int fb_real_multiply(fb_plan* p, const void* x, const void* y, void* out, void* 
 // ---- transverse (per-channel 2-D) transforms and masks (fastbox/filters.py:58-90) ---------------------------------
 int fb_fft_transverse(fb_plan* p, void* full_cube, int direction, void* stream) {
     FB_REQUIRE(p && full_cube, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(direction == 1 || direction == -1, "direction must be -1 (fftn) or +1 (ifftn)");
     hipStream_t s = (hipStream_t)stream;
     const double scale = direction > 0 ? 1.0 / ((double)p->N * p->N) : 1.0;
@@ -351,11 +405,13 @@ int fb_fft_transverse(fb_plan* p, void* full_cube, int direction, void* stream) 
 }
 int fb_real_to_complex(fb_plan* p, const void* real_cube, void* full_cube, void* stream) {
     FB_REQUIRE(p && real_cube && full_cube, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_real_to_complex_f32(p, real_cube, full_cube, s), fbi_real_to_complex_f64(p, real_cube, full_cube, s));
 }
 int fb_mask_transverse(fb_plan* p, void* full_cube, const void* mask2d, void* stream) {
     FB_REQUIRE(p && full_cube && mask2d, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_mask_xy_f32(p, full_cube, mask2d, s), fbi_mask_xy_f64(p, full_cube, mask2d, s));
 }
@@ -364,6 +420,7 @@ int fb_mask_transverse(fb_plan* p, void* full_cube, const void* mask2d, void* st
 int fb_beam_convolve(fb_plan* p, const void* field, const void* beam, void* work_a, void* work_b, void* out, int periodic,
                      int beam_ready, void* stream) {
     FB_REQUIRE(p && field && work_a && work_b && out, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(beam || beam_ready, "null beam cube");
     FB_REQUIRE(work_a != work_b, "the two work cubes must be distinct");
     FB_REQUIRE((periodic == 0 || periodic == 1) && (beam_ready == 0 || beam_ready == 1), "periodic, beam_ready must be 0 or 1");
@@ -377,17 +434,20 @@ int fb_beam_convolve(fb_plan* p, const void* field, const void* beam, void* work
 // ---- PCA foreground cleaning (fastbox/filters.py:93-183) -----------------------------------------------------
 int fb_channel_means(fb_plan* p, const void* cube, double* mean_dev, void* stream) {
     FB_REQUIRE(p && cube && mean_dev, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_channel_means_f32(p, cube, mean_dev, s), fbi_channel_means_f64(p, cube, mean_dev, s));
 }
 int fb_channel_covariance(fb_plan* p, const void* cube, const double* mean_dev, double* cov_dev, void* stream) {
     FB_REQUIRE(p && cube && mean_dev && cov_dev, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_channel_cov_f32(p, cube, mean_dev, cov_dev, s), fbi_channel_cov_f64(p, cube, mean_dev, cov_dev, s));
 }
 int fb_pca_clean(fb_plan* p, const void* cube, const double* mean_dev, const double* modes_dev, int nmodes, void* cube_out,
                  double* amps_dev, void* stream) {
     FB_REQUIRE(p && cube && mean_dev && cube_out && (modes_dev || nmodes == 0), "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_pca_clean_f32(p, cube, mean_dev, modes_dev, nmodes, cube_out, amps_dev, s),
                        fbi_pca_clean_f64(p, cube, mean_dev, modes_dev, nmodes, cube_out, amps_dev, s));
@@ -397,6 +457,7 @@ int fb_pca_clean(fb_plan* p, const void* cube, const double* mean_dev, const dou
 int fb_sky_realise_map(fb_plan* p, const void* amp2d, const void* re, const void* im, uint64_t seed, double monopole,
                        void* work_cplx, void* map_out, void* stream) {
     FB_REQUIRE(p && amp2d && work_cplx && map_out, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE((re == nullptr) == (im == nullptr), "give both re and im, or neither (device generator)");
     hipStream_t s = (hipStream_t)stream;
     int r = FB_DISPATCH(p, fbi_sky_colour_map_f32(p, amp2d, re, im, seed, work_cplx, s),
@@ -410,12 +471,14 @@ int fb_sky_realise_map(fb_plan* p, const void* amp2d, const void* re, const void
 }
 int fb_sky_normal_map(fb_plan* p, const void* unit, uint64_t seed, double mean, double std, void* map_out, void* stream) {
     FB_REQUIRE(p && map_out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_sky_normal_map_f32(p, unit, seed, mean, std, map_out, s),
                        fbi_sky_normal_map_f64(p, unit, seed, mean, std, map_out, s));
 }
 int fb_sky_gaussian_filter(fb_plan* p, void* map_inout, void* tmp, const double* weights, int radius, void* stream) {
     FB_REQUIRE(p && map_inout && tmp && weights, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_sky_gaussian_f32(p, map_inout, tmp, weights, radius, s),
                        fbi_sky_gaussian_f64(p, map_inout, tmp, weights, radius, s));
@@ -423,12 +486,14 @@ int fb_sky_gaussian_filter(fb_plan* p, void* map_inout, void* tmp, const double*
 int fb_sky_foreground_cube(fb_plan* p, const void* amps, const void* alpha, double alpha_scalar, const double* ratio,
                            void* cube_out, void* stream) {
     FB_REQUIRE(p && amps && ratio && cube_out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_sky_fg_cube_f32(p, amps, alpha, alpha_scalar, ratio, cube_out, s),
                        fbi_sky_fg_cube_f64(p, amps, alpha, alpha_scalar, ratio, cube_out, s));
 }
 int fb_sky_noise_cube(fb_plan* p, const double* sigma, const void* unit, uint64_t seed, void* cube_out, void* stream) {
     FB_REQUIRE(p && sigma && cube_out, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_sky_noise_cube_f32(p, sigma, unit, seed, cube_out, s),
                        fbi_sky_noise_cube_f64(p, sigma, unit, seed, cube_out, s));
@@ -437,7 +502,8 @@ int fb_sky_noise_cube(fb_plan* p, const double* sigma, const void* unit, uint64_
 // ---- slab-decomposed transforms -------------------------------------------------------------------
 #define FB_SLAB_CHECK(p, nparts) \
     FB_REQUIRE((p), "null pointer"); \
-    FB_REQUIRE((nparts) >= 1 && (p)->N % (nparts) == 0, "the number of slabs must divide N")
+    FB_REQUIRE((nparts) >= 1 && (p)->N % (nparts) == 0, "the number of slabs must divide N"); \
+    FB_USE_DEVICE(p)
 
 int fb_slab_forward_local(fb_plan* p, const void* real_local, void* half_local, int nparts, int pre_exp,
                           double* expsum_dev, void* stream) {
@@ -528,17 +594,26 @@ int64_t fb_slab_kspace_bytes(const fb_plan* p, int nparts) {
 
 int fb_debug_strided_pass(fb_plan* p, void* half, int axis, int mode, void* stream) {
     FB_REQUIRE(p && half, "null pointer");
+    FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_debug_pass_f32(p, half, axis, mode, s), fbi_debug_pass_f64(p, half, axis, mode, s));
 }
 
 int fb_set_tuning(fb_plan* p, int stagger_plain, int stagger_gen, int stagger_bin) {
     FB_REQUIRE(p, "null pointer");
+    FB_USE_DEVICE(p);
     p->stagger[0] = stagger_plain; p->stagger[1] = stagger_gen; p->stagger[2] = stagger_bin;
+    return FB_OK;
+}
+int fb_set_plane_batching(fb_plan* p, int planes, int streams) {
+    FB_REQUIRE(p, "null pointer");
+    FB_REQUIRE(planes >= -1 && streams >= 0 && streams <= 2, "planes >= -1 (auto), streams 0 (auto), 1 or 2");
+    p->plane_batch = planes; p->plane_streams = streams;
     return FB_OK;
 }
 int fb_debug_read_stamps(fb_plan* p, long long* host, int64_t count) {
     FB_REQUIRE(p && host && p->bin_partials, "no stamps");
+    FB_USE_DEVICE(p);
     FB_HIP(hipDeviceSynchronize());
     FB_HIP(hipMemcpy(host, p->bin_partials, (size_t)count * sizeof(long long), hipMemcpyDeviceToHost));
     return FB_OK;
@@ -546,11 +621,13 @@ int fb_debug_read_stamps(fb_plan* p, long long* host, int64_t count) {
 
 int fb_profile_select(fb_plan* p, unsigned mask) {
     FB_REQUIRE(p, "null pointer");
+    FB_USE_DEVICE(p);
     p->prof_mask = mask;
     return FB_OK;
 }
 int fb_profile_sample(fb_plan* p, int stride, int64_t* seen) {
     FB_REQUIRE(p, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(stride >= 1, "stride must be >= 1");
     if (seen) *seen = (int64_t)p->prof_seen;
     p->prof_stride = stride;
@@ -558,6 +635,7 @@ int fb_profile_sample(fb_plan* p, int stride, int64_t* seen) {
 }
 int fb_profile_start(fb_plan* p) {
     FB_REQUIRE(p, "null pointer");
+    FB_USE_DEVICE(p);
     p->prof_seen = 0;
     p->prof_used = 0;
     p->prof_cat.clear();
@@ -566,6 +644,7 @@ int fb_profile_start(fb_plan* p) {
 }
 int fb_profile_stop(fb_plan* p, void* stream, double* ms, int64_t* launches, int ncat) {
     FB_REQUIRE(p && ms && launches, "null pointer");
+    FB_USE_DEVICE(p);
     FB_REQUIRE(ncat >= FBK_NCAT, "ncat must be >= FB_PROF_NCAT");
     p->prof_on = false;
     FB_HIP(hipStreamSynchronize((hipStream_t)stream));

@@ -148,11 +148,12 @@ __device__ __forceinline__ cx<float> buf_load(__amdgpu_buffer_rsrc_t r, unsigned
 __device__ __forceinline__ cx<double> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, const cx<double>*) {
     return __builtin_bit_cast(cx<double>, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
 }
-__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, cx<float> v) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fb_u32x2, v), r, (int)voff, 0, 0);
+// AUX: cache policy bits of the instruction (0 default, 2 = nt: streaming data that nothing re-reads soon)
+template <int AUX = 0> __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, cx<float> v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fb_u32x2, v), r, (int)voff, 0, AUX);
 }
-__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, cx<double> v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fb_u32x4, v), r, (int)voff, 0, 0);
+template <int AUX = 0> __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, cx<double> v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fb_u32x4, v), r, (int)voff, 0, AUX);
 }
 
 constexpr int fb_min(int a, int b) { return a < b ? a : b; }
@@ -180,7 +181,14 @@ template <typename T> struct LineLayout {
 
 // ---- the stages --------------------------------------------------------------
 // tw: LDS table of forward twiddles W_M^j = exp(-2 pi i j / M), M = N * TWS.
-template <typename T, int N, int E, int SIGN, int TWS, int P, class Layout>
+// WAVE: the N/E threads of a line sit in one wavefront (contiguous-axis passes up to 512 complex points), so the
+// exchange needs no workgroup barrier -- a wave's LDS instructions execute in issue order; only the compiler has to
+// be kept from moving the reads above the writes.
+template <bool WAVE> __device__ __forceinline__ void exchange_sync() {
+    if constexpr (WAVE) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+template <typename T, int N, int E, int SIGN, int TWS, int P, class Layout, bool WAVE = false>
 __device__ __forceinline__ void fft_stages(cx<T> (&v)[E], const int t, const cx<T>* __restrict__ tw,
                                            const Layout& lds) {
     constexpr int REM = N / P;
@@ -213,11 +221,11 @@ __device__ __forceinline__ void fft_stages(cx<T> (&v)[E], const int t, const cx<
 #pragma unroll
             for (int q = 0; q < R; ++q) lds.at(j + q * P) = v[m + q * NB];
         }
-        __syncthreads();
+        exchange_sync<WAVE>();
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = lds.at(t + e * TPL);
-        __syncthreads();
-        fft_stages<T, N, E, SIGN, TWS, P * R, Layout>(v, t, tw, lds);
+        exchange_sync<WAVE>();
+        fft_stages<T, N, E, SIGN, TWS, P * R, Layout, WAVE>(v, t, tw, lds);
     }
 }
 

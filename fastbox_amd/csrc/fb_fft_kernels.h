@@ -34,6 +34,9 @@ template <typename T> constexpr int tile_cols(int n) {
                   64 / (n / strided_elems(n)));
 }
 
+#ifndef FB_GEN_STORE_AUX
+#define FB_GEN_STORE_AUX 0     // cache policy of the generator pass's stores (tuning: 2 = nt)
+#endif
 #ifndef FB_OCC
 #define FB_OCC(x) 1      // let the allocator use what the prefetching loop needs (no spills)
 #endif
@@ -204,6 +207,44 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                 cx<T> wl[ACC ? NJ : 1], wh[ACC ? NJ : 1];
                 auto lo = [&](int j) -> cx<T>& { if constexpr (ACC) return wl[j - J0]; else return v[j]; };
                 auto hi = [&](int j) -> cx<T>& { if constexpr (ACC) return wh[j - J0]; else return v[j + E2]; };
+                // amplitudes sqrt(P boxfactor / 2) (E |z|^2 = 1, fb_rng.h), fetched first so that the loads are in flight
+                // while the random numbers are computed: spread table rows |m_x| = k_x and N/2 - k_x of plane |m_y|,
+                // column k_z.  The source is wave-uniform: one loop per source, so that its loads are issued together.
+                T A0[NJ], A1[NJ];
+                auto A0v = [&](int j) -> T { return A0[j - J0]; };
+                auto A1v = [&](int j) -> T { return A1[j - J0]; };
+                {
+                    const T pf = (T)0.70710678118654752440;
+                    if (op.amp.sym) {
+                        const long long sym_step = (long long)TPL * (H + 1) * op.g.NZP;
+                        const T* sym0 = op.amp.sym + ((long long)t * (H + 1) + amy) * op.g.NZP + kz;
+                        const T* sym1 = op.amp.sym + ((long long)(H - t) * (H + 1) + amy) * op.g.NZP + kz;
+#pragma unroll
+                        for (int j = J0; j < J0 + NJ; ++j) {
+#ifdef FB_EXPERIMENT_NOAMP
+                            A0[j - J0] = pf; A1[j - J0] = pf;
+#else
+                            A0[j - J0] = sym0[j * sym_step] * pf;
+                            A1[j - J0] = sym1[-j * sym_step] * pf;
+#endif
+                        }
+                    } else if (op.amp.shell) {
+                        const int c2 = my * my + kz * kz;            // k_z <= N/2 is its own mode number
+#pragma unroll
+                        for (int j = J0; j < J0 + NJ; ++j) {
+                            const int kx = t + j * TPL, mh = kx - H;
+                            A0[j - J0] = op.amp.shell[kx * kx + c2] * pf;
+                            A1[j - J0] = op.amp.shell[mh * mh + c2] * pf;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = J0; j < J0 + NJ; ++j) {
+                            const int kx = t + j * TPL;
+                            A0[j - J0] = op.amp.dense[((long long)kx * op.g.NR + ky) * op.g.NZP + kz] * pf;
+                            A1[j - J0] = op.amp.dense[((long long)(kx + H) * op.g.NR + ky) * op.g.NZP + kz] * pf;
+                        }
+                    }
+                }
                 uint32_t X[NJ][4];
 #pragma unroll
                 for (int j = J0; j < J0 + NJ; ++j) {
@@ -244,39 +285,24 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                         }
                     }
                 }
-                // amplitudes: spread table rows |m_x| = k_x and N/2 - k_x of plane |m_y|, column k_z
-                const long long sym_step = (long long)TPL * (H + 1) * op.g.NZP;
-                const T* sym0 = op.amp.sym + ((long long)t * (H + 1) + amy) * op.g.NZP + kz;
-                const T* sym1 = op.amp.sym + ((long long)(H - t) * (H + 1) + amy) * op.g.NZP + kz;
-                const int c2 = my * my + kz * kz;            // k_z <= N/2 is its own mode number
-                const T pf = (T)0.70710678118654752440;      // E |z|^2 = 1 (fb_rng.h)
+                if (!op.vel_on) {
 #pragma unroll
-                for (int j = J0; j < J0 + NJ; ++j) {
-                    const int kx = t + j * TPL, kh = kx + H;
-                    T A0, A1;
-                    if (op.amp.sym) {
-                        A0 = sym0[j * sym_step] * pf;
-                        A1 = sym1[-j * sym_step] * pf;
-                    } else if (op.amp.shell) {
-                        const int mh = kx - H;
-#ifdef FB_EXPERIMENT_NOAMP
-                        A0 = pf; A1 = pf * (T)(mh * mh + c2 > 0 ? 1 : 0);
-#else
-                        A0 = op.amp.shell[kx * kx + c2] * pf;
-                        A1 = op.amp.shell[mh * mh + c2] * pf;
-#endif
-                    } else {
-                        A0 = op.amp.dense[((long long)kx * op.g.NR + ky) * op.g.NZP + kz] * pf;
-                        A1 = op.amp.dense[((long long)kh * op.g.NR + ky) * op.g.NZP + kz] * pf;
+                    for (int j = J0; j < J0 + NJ; ++j) {
+                        lo(j) = cscale(lo(j), A0[j - J0]);
+                        hi(j) = cscale(hi(j), A1[j - J0]);
                     }
-                    if (op.vel_on) {      // wave-uniform: the velocity field of the same realisation, i fac delta_k k_c / k^2
-                        const int cmp = op.vel_comp;
-                        const int kzc = kz < op.g.NZV ? kz : 0;                      // padding columns: any valid entry
-                        if constexpr (sizeof(T) == 4) {
-                            // single precision: k_c fac / k^2, k^2 = 4 pi^2 (s_x + (s_y + s_z)), hardware reciprocal
-                            const float syz = (float)(op.g.axis2[N + ky] + op.g.axis2[2 * N + kzc]);
-                            const int icf = cmp == 1 ? ky : kzc;
-                            const float kcf = (float)(op.g.ksc[cmp * N + icf] * op.vel_fac);
+                } else {      // wave-uniform: the velocity field of the same realisation, i fac delta_k k_c / k^2
+                    const int cmp = op.vel_comp;
+                    const int kzc = kz < op.g.NZV ? kz : 0;                      // padding columns: any valid entry
+                    if constexpr (sizeof(T) == 4) {
+                        // single precision: k_c fac / k^2, k^2 = 4 pi^2 (s_x + (s_y + s_z)), hardware reciprocal
+                        const float syz = (float)(op.g.axis2[N + ky] + op.g.axis2[2 * N + kzc]);
+                        const int icf = cmp == 1 ? ky : kzc;
+                        const float kcf = (float)(op.g.ksc[cmp * N + icf] * op.vel_fac);
+#pragma unroll
+                        for (int j = J0; j < J0 + NJ; ++j) {
+                            const int kx = t + j * TPL, kh = kx + H;
+                            const T A0 = A0v(j), A1 = A1v(j);
                             const float s0 = (float)op.g.axis2[kx] + syz, s1 = (float)op.g.axis2[kh] + syz;
                             float k0 = cmp == 0 ? (float)(op.g.ksc[kx] * op.vel_fac) : kcf;
                             float k1 = cmp == 0 ? (float)(op.g.ksc[kh] * op.vel_fac) : kcf;
@@ -286,16 +312,18 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                             const float m1 = s1 > 0.f ? A1 * k1 * __builtin_amdgcn_rcpf(39.47841760435743f * s1) : 0.f;
                             lo(j) = cx<T>{-lo(j).y * m0, lo(j).x * m0};
                             hi(j) = cx<T>{-hi(j).y * m1, hi(j).x * m1};
-                        } else {
-                            const double ay = op.g.axis2[N + ky], az = op.g.axis2[2 * N + kzc];   // kmag_exact's order
+                        }
+                    } else {
+                        const double ay = op.g.axis2[N + ky], az = op.g.axis2[2 * N + kzc];   // kmag_exact's order
+#pragma unroll
+                        for (int j = J0; j < J0 + NJ; ++j) {
+                            const int kx = t + j * TPL, kh = kx + H;
+                            const T A0 = A0v(j), A1 = A1v(j);
                             lo(j) = velocity_of<T>(op.g, cmp, op.vel_fac, cmp == 0 ? kx : (cmp == 1 ? ky : kzc),
                                                    (op.g.axis2[kx] + ay) + az, cscale(lo(j), A0));
                             hi(j) = velocity_of<T>(op.g, cmp, op.vel_fac, cmp == 0 ? kh : (cmp == 1 ? ky : kzc),
                                                    (op.g.axis2[kh] + ay) + az, cscale(hi(j), A1));
                         }
-                    } else {
-                        lo(j) = cscale(lo(j), A0);
-                        hi(j) = cscale(hi(j), A1);
                     }
                 }
                 if constexpr (ACC) {
@@ -308,7 +336,14 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     }
                 }
             };
-            column(col, std::integral_constant<int, 0>{}, std::integral_constant<int, E2>{}, std::false_type{});
+            // (two half batches: Philox's 64-bit products are live for a whole batch, and with all E/2 calls interleaved
+            // the pass does not fit its 64 VGPRs)
+            if constexpr (E2 >= 4) {
+                column(col, std::integral_constant<int, 0>{}, std::integral_constant<int, E2 / 2>{}, std::false_type{});
+                column(col, std::integral_constant<int, E2 / 2>{}, std::integral_constant<int, E2 / 2>{}, std::false_type{});
+            } else {
+                column(col, std::integral_constant<int, 0>{}, std::integral_constant<int, E2>{}, std::false_type{});
+            }
             // packed, tile 0 (wave-uniform): column 0 = (k_z = 0 plane) + i (k_z = N/2 plane), both Hermitian planes
             if (pk0) {
                 column(H, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::true_type{});
@@ -398,7 +433,10 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             cx<T>* dst = a.out + ((long long)by * out_outer + bx * TZ) + tbase;
             const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
 #pragma unroll
-            for (int e = 0; e < E; ++e) buf_store(make_rsrc(dst + eoff(e, a.blk_out)), voff, cscale(v[e], a.scale));
+            for (int e = 0; e < E; ++e) {
+                if constexpr (MODE == SMODE_GEN) buf_store<FB_GEN_STORE_AUX>(make_rsrc(dst + eoff(e, a.blk_out)), voff, cscale(v[e], a.scale));
+                else buf_store(make_rsrc(dst + eoff(e, a.blk_out)), voff, cscale(v[e], a.scale));
+            }
         }
         if constexpr (smode_bins(MODE)) {
             // Re-stage p = |X|^2 through LDS so that each lane bins E consecutive elements of
@@ -557,11 +595,11 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 // out[q] = sum_r partial[q][r], fixed order: one workgroup per value
 // (workgroup nvals, if launched: out[nvals] = sum of the single column partial2[nrows2], 0 if that is null --
 // the log-normal mean's block sums ride along with the bin sums in one launch)
-static __global__ __launch_bounds__(256) void k_sum_columns(const double* __restrict__ partial, long long nrows,
-                                                             int nvals, double* __restrict__ out,
-                                                             const double* __restrict__ partial2, long long nrows2) {
-    __shared__ double sh[256];
-    const int q = blockIdx.x;
+static __global__ __launch_bounds__(1024) void k_sum_columns(const double* __restrict__ partial, long long nrows,
+                                                              int nvals, double* __restrict__ out,
+                                                              const double* __restrict__ partial2, long long nrows2) {
+    __shared__ double sh[1024];
+    const int q = blockIdx.x, nt = blockDim.x;       // nt: a power of two, 64 .. 1024
     const double* src = partial + (size_t)q * nrows;
     if (q == nvals) {
         if (!partial2) { if (threadIdx.x == 0) out[q] = 0.0; return; }
@@ -570,15 +608,15 @@ static __global__ __launch_bounds__(256) void k_sum_columns(const double* __rest
     // fixed summation order (thread-strided, 8 independent chains so that the loads pipeline)
     double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long r = threadIdx.x;
-    for (; r + 7 * 256 < nrows; r += 8 * 256) {
+    for (; r + 7 * nt < nrows; r += 8 * nt) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] += src[r + u * 256];
+        for (int u = 0; u < 8; ++u) c[u] += src[r + u * nt];
     }
-    for (int u = 0; r < nrows; r += 256, ++u) c[u & 7] += src[r];
+    for (int u = 0; r < nrows; r += nt, ++u) c[u & 7] += src[r];
     const double s = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
     sh[threadIdx.x] = s;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = nt >> 1; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
@@ -613,14 +651,24 @@ __global__ __launch_bounds__(256) void k_bin_packed_plane(const cx<T>* __restric
         const T p0 = x0.x * x0.x + x0.y * x0.y, p1 = x1.x * x1.x + x1.y * x1.y;
         const int b0 = have ? bin_of_mode(bg, g, lbins, lthr, kx, ky, 0) : nb;
         const int b1 = have ? bin_of_mode(bg, g, lbins, lthr, kx, ky, N >> 1) : nb;
-        wave_flush(b0, (double)p0, (double)p0 * (double)p0, have && b0 < nb, row);
-        wave_flush(b1, (double)p1, (double)p1 * (double)p1, have && b1 < nb, row);
+        wave_flush(b0, p0, p0 * p0, have && b0 < nb, row);       // sums of a wave in T (DPP), rows in fp64, as the main pass
+        wave_flush(b1, p1, p1 * p1, have && b1 < nb, row);
     }
     __syncthreads();
     for (int i = tid; i < 2 * nb; i += 256)
         partial[(size_t)i * stride + col0 + blockIdx.x] = (acc[i] + acc[2 * nb + i]) + (acc[4 * nb + i] + acc[6 * nb + i]);
 }
 
+// exp() of the log-normal transform (box.py:457).  -DFB_FAST_EXP: hardware 2^x on x log2(e) for single precision
+// (relative error ~ |x| 2^-24 from the rounded product plus 1 ulp) instead of libm's expf.
+__device__ __forceinline__ double fb_exp(double x) { return exp(x); }
+__device__ __forceinline__ float fb_exp(float x) {
+#ifdef FB_FAST_EXP
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#else
+    return expf(x);
+#endif
+}
 enum { ZMODE_C2C = 0, ZMODE_R2C = 1, ZMODE_C2R = 2, ZMODE_C2R2C = 3 };
 // C2R2C: inverse z pass, write the real field, then (optionally exp() and) forward z pass of the
 // same line from registers: realise_density's last pass fused with the power spectrum's first,
@@ -656,6 +704,11 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
     constexpr int TWS = (MODE == ZMODE_C2C) ? 1 : 2;
     constexpr int M = NF * TWS;
     constexpr int LP = LineLayout<T>::padded(NF);
+#ifdef FB_CONTIG_BARRIERS
+    constexpr bool WAVE = false;
+#else
+    constexpr bool WAVE = TPL <= 64;       // a line's threads share a wavefront: exchanges without workgroup barriers
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<T>* lines = reinterpret_cast<cx<T>*>(smem);
     cx<T>* twl = lines + LPW * LP;
@@ -685,7 +738,7 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
             cx<T> wd = cmul(w, d);
             v[e] = cx<T>{s.x - wd.y, s.y + wd.x};
         }
-        fft_stages<T, NF, E, +1, TWS, 1>(v, t, twl, lay);
+        fft_stages<T, NF, E, +1, TWS, 1, LineLayout<T>, WAVE>(v, t, twl, lay);
         if (valid) {
             cx<T>* out = reinterpret_cast<cx<T>*>(reinterpret_cast<T*>(a.out) + line * a.out_pitch);
 #pragma unroll
@@ -702,14 +755,15 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
         if (a.pre_exp) {
 #pragma unroll
             for (int e = 0; e < E; ++e)
-                if (valid) { v[e].x = exp(v[e].x); v[e].y = exp(v[e].y); esum += (double)v[e].x + (double)v[e].y; }
+                if (valid) { v[e].x = fb_exp(v[e].x); v[e].y = fb_exp(v[e].y); esum += (double)v[e].x + (double)v[e].y; }
         }
-        __syncthreads();
-        fft_stages<T, NF, E, -1, TWS, 1>(v, t, twl, lay);
+        if constexpr (MODE == ZMODE_R2C || !WAVE) __syncthreads();      // R2C: the twiddles; C2R2C: lines[] is this wave's own
+        else exchange_sync<true>();
+        fft_stages<T, NF, E, -1, TWS, 1, LineLayout<T>, WAVE>(v, t, twl, lay);
         // untangle: X[k] = (Z[k] + conj Z[n-k])/2 - (i/2) W_N^k (Z[k] - conj Z[n-k])
 #pragma unroll
         for (int e = 0; e < E; ++e) lay.at(t + e * TPL) = v[e];
-        __syncthreads();
+        exchange_sync<WAVE>();
         if (valid) {
             cx<T>* out = (MODE == ZMODE_C2R2C)
                 ? reinterpret_cast<cx<T>*>(a.out2) + (line + (a.in_skip ? line / a.in_skip : 0)) * a.in_pitch
@@ -744,8 +798,8 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = valid ? in[t + e * TPL] : cx<T>{0, 0};
         __syncthreads();
-        if (sign_c2c < 0) fft_stages<T, NF, E, -1, TWS, 1>(v, t, twl, lay);
-        else              fft_stages<T, NF, E, +1, TWS, 1>(v, t, twl, lay);
+        if (sign_c2c < 0) fft_stages<T, NF, E, -1, TWS, 1, LineLayout<T>, WAVE>(v, t, twl, lay);
+        else              fft_stages<T, NF, E, +1, TWS, 1, LineLayout<T>, WAVE>(v, t, twl, lay);
         if (valid) {
             cx<T>* out = reinterpret_cast<cx<T>*>(a.out) + (line + (a.out_skip ? line / a.out_skip : 0)) * a.out_pitch;
 #pragma unroll

@@ -253,6 +253,20 @@ __device__ __forceinline__ void wave_flush(int b, double s1, double s2, bool hav
     }
 }
 
+// the same with the wave's sums formed in single precision (six DPP adds instead of twelve cross-lane moves)
+__device__ __forceinline__ void wave_flush(int b, float s1, float s2, bool have, double* row) {
+    unsigned long long rem = __ballot(have);
+    const int lane = threadIdx.x & 63;
+    while (rem) {
+        const int lead = __ffsll((long long)rem) - 1;
+        const int bl = __shfl(b, lead, 64);
+        const bool mine = have && b == bl;
+        const float r1 = wave_sum(mine ? s1 : 0.f), r2 = wave_sum(mine ? s2 : 0.f);
+        if (lane == 0) { row[2 * bl] += (double)r1; row[2 * bl + 1] += (double)r2; }
+        rem &= ~__ballot(mine);
+    }
+}
+
 // block partial sums of f(x); OP 0: x, 1: x^2, 2: exp(x) (also written to out)
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void k_reduce_real(const T* __restrict__ in, T* __restrict__ out, long long n,

@@ -33,7 +33,14 @@ class _Buffer(object):
     def __del__(self):
         pool = self.pool
         if pool is not None and self.ptr:
-            pool.setdefault(self.nbytes, []).append(self.ptr)
+            closed = pool.get("closed")
+            if closed is not None:                 # the engine is gone: nothing will reuse the buffer
+                try:
+                    closed.fb_free(ctypes.c_void_p(self.ptr))
+                except Exception:
+                    pass
+            else:
+                pool.setdefault(self.nbytes, []).append(self.ptr)
             self.ptr = None
 
 
@@ -163,10 +170,12 @@ class DeviceArray(NDArrayOperatorsMixin):
         return "DeviceArray(kind=%s, shape=%s, precision=%s)" % (self.kind, self.shape, self.engine.precision)
 
 
-def new_stream():
+def new_stream(device=None):
     """A fresh non-blocking HIP stream (raw handle) for ``CosmoBox(..., stream=...)``: independent
     boxes on different streams overlap on the GPU (compute-bound passes of one with memory-bound
-    passes of the other)."""
+    passes of the other).  ``device``: the GPU the stream is for (default: the current one)."""
+    if device is not None:
+        _lib.call("fb_device_set", int(device))
     s = ctypes.c_void_p()
     _lib.call("fb_stream_create", ctypes.byref(s))
     return s.value
@@ -212,10 +221,10 @@ class Engine(object):
     def close(self):
         if getattr(self, "_plan", None) is not None and self._plan:
             self.sync()
-            for ptrs in self._pool.values():
-                for p in ptrs:
-                    self.lib.fb_free(ctypes.c_void_p(p))
-            self._pool = {}
+            self._work_half = None
+            self._amp_dense = None
+            self.release_idle_buffers()
+            self._pool["closed"] = self.lib        # buffers of fields that outlive the engine are freed when dropped
             if self._res_dev:
                 self.lib.fb_free(ctypes.c_void_p(self._res_dev))
                 self._res_dev = None
@@ -234,6 +243,7 @@ class Engine(object):
         if free:
             return _Buffer(free.pop(), nbytes, self._pool)
         p = ctypes.c_void_p()
+        _lib.call("fb_device_set", self.device)            # fb_malloc serves the current device
         try:
             _lib.call("fb_malloc", ctypes.byref(p), nbytes)
         except _lib.FastBoxError as e:
@@ -251,8 +261,8 @@ class Engine(object):
 
     def release_idle_buffers(self):
         """Give the pooled (currently unused) device buffers back to the driver."""
-        for ptrs in self._pool.values():
-            while ptrs:
+        for key, ptrs in self._pool.items():
+            while key != "closed" and ptrs:
                 self.lib.fb_free(ctypes.c_void_p(ptrs.pop()))
 
     def empty(self, kind, as_complex=False):
@@ -260,6 +270,11 @@ class Engine(object):
 
     def sync(self):
         _lib.call("fb_stream_sync", self.stream)
+
+    def set_plane_batching(self, planes=-1, streams=0):
+        """x-planes per batch of the y/z passes (-1: sized to the Infinity Cache for one box on the GPU; give each of
+        several concurrently running boxes its share) and 1 | 2 streams for alternate batches (0: by grid size)."""
+        _lib.call("fb_set_plane_batching", self._plan, int(planes), int(streams))
 
     def upload(self, arr, kind):
         """Host ndarray (N,N,N) -> device.  kind REAL or FULL."""
@@ -505,6 +520,7 @@ class Engine(object):
         still unfetched by then is brought to the host first."""
         if self._res_dev is None:
             p = ctypes.c_void_p()
+            _lib.call("fb_device_set", self.device)
             _lib.call("fb_malloc", ctypes.byref(p), self.RES_SLOTS * self.RES_STRIDE * 8)
             self._res_dev = p.value
             self._res_host = np.zeros((self.RES_SLOTS, self.RES_STRIDE))

@@ -21,6 +21,20 @@ Each ordered pair of ranks exchanges (N/P)(N/P)(pitch) complex values; with P = 
 a GPU carry one peer each.  The device noise depends on global mode indices only, so the field is
 identical for every P (tests compare P = 1, 2, 4).
 
+Communication / compute overlap: a Monte-Carlo loop has independent realisations, so the exchanges of one are
+hidden behind the passes of its neighbours -- ``realise_and_power(wait=False)`` keeps up to three realisations in
+flight on this rank,
+
+  compute stream :  GEN(i)   turn(i-1)   BIN(i-2)   GEN(i+1)   turn(i)   BIN(i-1)  ...
+  RCCL stream    :     x1(i) ........ x2(i-1) .........   x1(i+1) ...... x2(i) ....
+
+(GEN = generator + x pass of the k-slab, x1 = its all-to-all, turn = y pass, fused z passes, y pass of the x-slab,
+x2 = the all-to-all back, BIN = x pass with the shell binning): both all-to-alls of a realisation run as asynchronous
+collectives while the compute stream works on another realisation, with three rotating buffer pairs.  The kernels are
+those of the synchronous path, the fields are bit-identical, and -- unlike a chunked exchange inside one transform,
+which cannot start before the first pass has produced every destination's block -- the FIRST exchange is hidden too.
+Bin sums stay on the device (a ring of records, all-reduced asynchronously) until ``result()`` is called.
+
 The per-rank arithmetic is behind a small "ops" interface: ``HipSlabOps`` drives libfastbox_hip (no
 CPU fallback); tests inject a numpy implementation to exercise the exchange logic under gloo.
 """
@@ -152,6 +166,12 @@ class SlabBox(object):
         self._half = self.ops.new_half_local()
         self.delta_x = None
         self._bin_cache, self._bins_set = {}, None
+        # pipelined Monte-Carlo steps (realise_and_power(wait=False)): rotating buffer pairs, the real slab and the
+        # ring of result records are allocated once, on first use
+        self._pairs = None
+        self._real_mc = None
+        self._ring, self._ring_next = None, 0
+        self._inflight, self._retired = [], []     # _Ticket objects, oldest first
 
     def _fused(self, call):
         """Run the exchange-buffer-addressing form of a y pass if the backend has it and the rank count allows it
@@ -244,10 +264,17 @@ class SlabBox(object):
         self.ops.x_bin(kslab, self._res)
         return self._res
 
-    def realise_and_power(self, nbins=20, kbins=None, lognormal=False):
+    def realise_and_power(self, nbins=20, kbins=None, lognormal=False, wait=True):
         """``realise_density()`` followed by ``binned_power_spectrum(lognormal=...)`` of the new field, as the
         Monte-Carlo loop does, with the z passes of the two fused: the real slab is written once, not read back.
-        Returns (kc, pk, stddev); ``self.delta_x`` holds the slab."""
+        Returns (kc, pk, stddev); ``self.delta_x`` holds the slab.
+
+        ``wait=False``: returns a ticket at once; its ``result()`` gives the triple.  With several ranks up to three
+        realisations are in flight and their all-to-alls overlap the passes of the others (module docstring);
+        ``flush()`` issues whatever is still outstanding, ``result()`` does so implicitly."""
+        if not wait and self.world > 1:
+            return self._submit(nbins, kbins, lognormal)
+        self._drain()
         bins, kc = self._pk_setup(nbins, kbins)
         nb = bins.size
         if lognormal and not bins[0] > 0.:
@@ -263,7 +290,104 @@ class SlabBox(object):
             send = self._pk_local(real, lognormal, nb)
         other = self._kslab if send is self._xbuf else self._xbuf
         res = self._pk_finish(self._exchange(send, other), nb)
+        if not wait:
+            return _Deferred(self, res, kc, nb, lognormal)
         return self._finish_power(res, kc, nb, lognormal)
+
+    # -- pipelined Monte-Carlo steps ----------------------------------------------------------
+    RING = 64                                      # result records kept on the device before they must be fetched
+
+    def _exchange_async(self, send, recv):
+        """All-to-all as an asynchronous collective: returns a handle whose ``wait()`` makes the compute stream wait
+        for it (None: nothing to wait for).  gloo with device tensors (single-GPU rehearsal) stages synchronously."""
+        if self._host_staged(send):
+            self._exchange(send, recv)
+            return None
+        return self._dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group, async_op=True)
+
+    def _all_reduce_async(self, t):
+        if self._host_staged(t):
+            self._all_reduce(t)
+            return None
+        return self._dist.all_reduce(t, group=self.group, async_op=True)
+
+    def _mc_buffers(self, nb):
+        if self._pairs is None:
+            # pair 0 reuses the synchronous path's buffers; a realisation owns its pair from GEN to BIN
+            self._pairs = [(self._kslab, self._xbuf)] + [(self.ops.new_kslab(), self.ops.new_kslab()) for _ in range(2)]
+            self._real_mc = self.ops.new_real()
+        if self._ring is None or self._ring.shape[1] != 2 * nb + 1:
+            self._drain()
+            self._fetch_retired()
+            self._ring = self.ops.new_results(self.RING * (2 * nb + 1)).view(self.RING, 2 * nb + 1)
+            self._ring_next = 0
+
+    def _turn(self, t):
+        if t.w1 is not None:
+            t.w1.wait()
+        a, b = t.pair
+        real = self._real_mc
+        if not self._fused(lambda: self.ops.turnaround(b, self._half, real, a, t.lognormal, t.res[2 * t.nb:])):
+            self.ops.unpack(b, self._half)
+            self.ops.inverse_local(self._half, real)
+            self.ops.forward_local(real, self._half, t.lognormal, t.res[2 * t.nb:])
+            self.ops.pack(self._half, a)
+        self.delta_x = real
+        t.w2 = self._exchange_async(a, b)
+        t.state = "turned"
+
+    def _bin(self, t):
+        if t.w2 is not None:
+            t.w2.wait()
+        self.ops.x_bin(t.pair[1], t.res)
+        t.w3 = self._all_reduce_async(t.res)
+        t.state = "binned"
+
+    def _drain(self):
+        """Issue the remaining stages of every realisation in flight, oldest first."""
+        for t in self._inflight:
+            if t.state == "gen":
+                self._turn(t)
+        for t in self._inflight:
+            if t.state == "turned":
+                self._bin(t)
+        self._retired += self._inflight
+        self._inflight = []
+
+    def _fetch_retired(self):
+        for t in self._retired:
+            t.fetch()
+        self._retired = []
+
+    def _submit(self, nbins, kbins, lognormal):
+        bins, kc = self._pk_setup(nbins, kbins)
+        nb = bins.size
+        if lognormal and not bins[0] > 0.:
+            raise ValueError("the fused log-normal P(k) needs kbins[0] > 0")
+        self._mc_buffers(nb)
+        if self._ring_next and self._ring_next % self.RING == 0:
+            self._drain()                                  # the ring is about to wrap: fetch what is pending first
+            self._fetch_retired()
+        tk = _Ticket(self, kc, nb, lognormal, self._pairs[self._realisation % 3],
+                     self._ring[self._ring_next % self.RING])
+        self._ring_next += 1
+        # compute stream: GEN(i), turn(i-1), BIN(i-2); the collectives follow their producers on the RCCL stream
+        self.ops.x_generate(tk.pair[0], self.seed, self._realisation)
+        self._realisation += 1
+        tk.w1 = self._exchange_async(tk.pair[0], tk.pair[1])
+        fl = self._inflight
+        if fl and fl[-1].state == "gen":
+            self._turn(fl[-1])
+        if len(fl) > 1 and fl[-2].state == "turned":
+            self._bin(fl[-2])
+        fl.append(tk)
+        while fl and fl[0].state == "binned":              # its buffer pair is free again
+            self._retired.append(fl.pop(0))
+        return tk
+
+    def flush(self):
+        """Issue the remaining stages of every realisation submitted with ``wait=False``."""
+        self._drain()
 
     def _finish_power(self, res, kc, nb, lognormal):
         self._all_reduce(res)                                     # 2*nbins+1 doubles
@@ -285,6 +409,44 @@ class SlabBox(object):
         send = self._pk_local(real, lognormal, nb)
         res = self._pk_finish(self._exchange(send, self._kslab), nb)
         return self._finish_power(res, kc, nb, lognormal)
+
+
+class _Ticket(object):
+    """One pipelined realisation + P(k) of a SlabBox (see SlabBox._submit)."""
+
+    def __init__(self, box, kc, nb, lognormal, pair, res):
+        self.box, self.kc, self.nb, self.lognormal, self.pair, self.res = box, kc, nb, lognormal, pair, res
+        self.state, self.w1, self.w2, self.w3 = "gen", None, None, None
+        self._host = None
+
+    def fetch(self):
+        if self._host is None:
+            if self.state != "binned":
+                self.box._drain()
+            if self.w3 is not None:
+                self.w3.wait()
+            self._host = self.res.detach().cpu().numpy().copy()
+            if self in self.box._retired:
+                self.box._retired.remove(self)
+        return self._host
+
+    def result(self):
+        h, nb, box = self.fetch(), self.nb, self.box
+        s1, s2, esum = h[0:2 * nb:2].copy(), h[1:2 * nb:2].copy(), h[2 * nb]
+        if self.lognormal:
+            mean = esum / float(box.N) ** 3
+            s1, s2 = s1 / mean ** 2, s2 / mean ** 4
+        return (self.kc,) + hostgeom.finish_bins(box.ops.bin_counts(), s1, s2, box.boxfactor)
+
+
+class _Deferred(object):
+    """wait=False on a single rank: the step has been queued, the bin sums are fetched on ``result()``."""
+
+    def __init__(self, box, res, kc, nb, lognormal):
+        self.box, self.res, self.kc, self.nb, self.lognormal = box, res, kc, nb, lognormal
+
+    def result(self):
+        return self.box._finish_power(self.res, self.kc, self.nb, self.lognormal)
 
 
 def run_virtual(boxes, fn_local, fn_finish):

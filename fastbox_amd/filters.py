@@ -62,21 +62,23 @@ def pca_filter(field, nmodes, fit_powerlaw=False, return_filter=False, box=None)
     cube = _as_cube(field, box)
     eng = cube.engine
     N = eng.N
-    mean = _channel_means(eng, cube)
+    mean_true = _channel_means(eng, cube)
+    mean = mean_true
     if fit_powerlaw:
-        # filters.py:146-154: replace the mean spectrum by a power-law fit of it (N numbers: host)
+        # filters.py:146-154: x = d - (power-law fit of the mean spectrum) is what the modes are projected out of and
+        # what is added back; np.cov(x) (:157-158) still centres every channel on its own mean, so the covariance
+        # is taken about the TRUE channel means -- the fit only enters the projection step (N numbers: host)
         from scipy.optimize import curve_fit
         h = np.empty(N)
-        _lib.call("fb_memcpy_d2h", h.ctypes.data_as(ctypes.c_void_p), mean.ptr, h.nbytes, eng.stream)
+        _lib.call("fb_memcpy_d2h", h.ctypes.data_as(ctypes.c_void_p), mean_true.ptr, h.nbytes, eng.stream)
         freqs = np.linspace(1., 10., N)
 
         def fn(nu, amp, beta):
             return amp * (nu / nu[0]) ** beta
         pfit, _ = curve_fit(fn, freqs, h, p0=[h[0], -2.7])
-        h = np.ascontiguousarray(fn(freqs, pfit[0], pfit[1]))
-        _lib.call("fb_memcpy_h2d", mean.ptr, h.ctypes.data_as(ctypes.c_void_p), h.nbytes, eng.stream)
+        mean = eng.upload_raw(np.ascontiguousarray(fn(freqs, pfit[0], pfit[1])))
     cov_dev = eng._alloc_bytes(N * N * 8)
-    _lib.call("fb_channel_covariance", eng._plan, cube.ptr, mean.ptr, cov_dev.ptr, eng.stream)
+    _lib.call("fb_channel_covariance", eng._plan, cube.ptr, mean_true.ptr, cov_dev.ptr, eng.stream)
     cov = np.empty((N, N))
     _lib.call("fb_memcpy_d2h", cov.ctypes.data_as(ctypes.c_void_p), cov_dev.ptr, cov.nbytes, eng.stream)
     # filters.py:161-169: eigenvectors by decreasing eigenvalue, keep nmodes

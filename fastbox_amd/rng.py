@@ -49,8 +49,11 @@ def box_muller(a, b, dtype=np.float64):
         r = np.sqrt(dt(-1.3862943611198906) * np.log2(u1))
     else:
         r = np.sqrt(-2.0 * np.log(u1))
-    ang = dt(2.0 * np.pi) * u2
-    return (r * np.cos(ang)).astype(dtype), (r * np.sin(ang)).astype(dtype)
+    # the device's sine / cosine take the angle in revolutions (v_sin_f32, sincospi), i.e. they see u2 itself: the
+    # angle is formed in double here -- 2 pi rounded to float32 is 2.8e-8 too large, which would bias cos by that
+    # much on average and, summed coherently over 10^8 modes, put a spike at the origin of a 512^3 field
+    ang = 2.0 * np.pi * u2.astype(np.float64)
+    return (r * np.cos(ang).astype(dtype)).astype(dtype), (r * np.sin(ang).astype(dtype)).astype(dtype)
 
 
 def half_spectrum_noise(N, seed, realisation, dtype=np.float64, planes=None):

@@ -282,6 +282,11 @@ int fb_slab_x_bin(fb_plan* plan, void* kslab, int nparts, int part, double* resu
 /* start-up stagger of the second resident workgroup generation of the strided passes, in units of
  * 64 shader cycles, per pass kind (0 = off); see k_fft_strided */
 int fb_set_tuning(fb_plan* plan, int stagger_plain, int stagger_gen, int stagger_bin);
+/* The y and z passes of a transform run x-plane batch by x-plane batch so that a batch stays in the 256 MiB Infinity
+ * Cache between them.  planes = -1: sized for ONE box using the GPU (default); when several boxes run concurrently on
+ * their own streams, give each its share (e.g. 64 planes of a 512^3 box for two).  0 = whole box in one go.
+ * streams = 2 sends alternate batches to a second stream of the plan; 0 = by grid size. */
+int fb_set_plane_batching(fb_plan* plan, int planes, int streams);
 /* tuning aid: a single strided FFT pass over a half spectrum (axis 0 = x, 1 = y;
  * mode 0 plain in place, 1 fused generator, 2 fused binning without store) */
 int fb_debug_strided_pass(fb_plan* plan, void* half, int axis, int mode, void* stream);
@@ -298,6 +303,10 @@ int fb_stream_create(void** stream);     /* a non-blocking hipStream_t, for runn
 int fb_stream_destroy(void* stream);
 int fb_stream_sync(void* stream);
 int fb_device_count(int* count);
+/* Make `device` the calling thread's current HIP device.  Every entry point that takes a plan does this for the plan's
+ * device itself; bindings call it before the plan-less helpers above (fb_malloc, fb_stream_create) when they serve a
+ * box on a device other than the current one. */
+int fb_device_set(int device);
 
 #ifdef __cplusplus
 }

@@ -162,6 +162,41 @@ def tophat_window1(k, R):
         return (3. / x ** 3.) * (np.sin(x) - x * np.cos(x))
 
 
+def tophat_window(k, R):
+    """box.py:595-612: the window squared."""
+    return tophat_window1(k, R) ** 2.
+
+
+def sigma_R(g, delta_k, R, h):
+    """box.py:657-683: sqrt(int k^2 P(k) W^2(k R/h) dk / 2 pi^2) by Simpson's rule over the non-NaN bins of the
+    default binned power spectrum (scipy.integrate.simps of the reference's day = simpson)."""
+    from scipy.integrate import simpson
+    k, pk, stddev = binned_power_spectrum(g, delta_k)
+    good = ~np.isnan(pk)
+    pk, k = pk[good], k[good]
+    y = k ** 2. * pk * tophat_window(k, R / h)
+    return np.sqrt(simpson(y, x=k) / (2. * np.pi ** 2.))
+
+
+def sampling_report(g, delta_x, delta_k, pk_fn, h):
+    """The nine numbers box.py:871-928 (test_sampling_error) prints, in print order: sigma8 from the realisation,
+    theory in the box's k-window, theory over a wide window, real-space sigma8, their ratio, the same three for
+    R = 20 Mpc/h, std(delta_x)."""
+    from scipy.integrate import simpson
+    s8_real = sigma_R(g, delta_k, 8., h)
+    _k = np.linspace(g['kmin'], g['kmax'], int(5e3))
+    _y = np.nan_to_num(_k ** 2. * pk_fn(_k) * tophat_window(_k, 8.0 / h))
+    s8_th_win = np.sqrt(simpson(_y, x=_k) / (2. * np.pi ** 2.))
+    _k2 = np.logspace(-5, 2, int(5e4))
+    _y2 = np.nan_to_num(_k2 ** 2. * pk_fn(_k2) * tophat_window(_k2, 8.0 / h))
+    s8_th_full = np.sqrt(simpson(_y2, x=_k2) / (2. * np.pi ** 2.))
+    s8_realspace = np.std(smooth_field(g, delta_k, 8.0, h))
+    s20_realspace = np.std(smooth_field(g, delta_k, 20.0, h))
+    s20_real = sigma_R(g, delta_k, 20., h)
+    return np.array([s8_real, s8_th_win, s8_th_full, s8_realspace, 1. / (s8_real / s8_realspace),
+                     s20_real, s20_realspace, 1. / (s20_real / s20_realspace), np.std(delta_x)])
+
+
 def smooth_field(g, field_k, R, h):
     """box.py:651-655 (R in Mpc/h)."""
     dk = field_k * tophat_window1(k_magnitude(g), R / h)

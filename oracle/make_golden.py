@@ -37,7 +37,7 @@ CASES = [
     ("n64_l100", 64, (1e2, 1e2, 1e2), 0.0, 11, 4, "pk"),
     ("n64_l4000", 64, 4e3, 0.8, 10, 4, "pk"),
     ("n128_l1000", 128, 1e3, 0.0, 14, 8, "pk"),
-    ("n256_l1000", 256, 1e3, 0.0, 14, 16, "pk"),
+    ("n256_l1000", 256, 1e3, 0.0, 14, 16, "all"),       # BASELINE configs[2]'s chain at the largest size that is cheap here
     # BASELINE.json configs[1] (the size the metric is quoted on): ~25 GB and ~10 min of host work
     ("n512_l1000", 512, 1e3, 0.0, 14, 32, "pkln"),
 ]
@@ -74,6 +74,27 @@ def capture(ref, name, N, box_scale, redshift, seed, s, what):
     out["pkkb_k"], out["pkkb_p"], out["pkkb_e"] = box.binned_power_spectrum(kbins=kb)
     s1, s2 = box.test_parseval()
     out["parseval"] = np.array([s1, s2])
+    # sigma_R from the realisation's binned spectrum, the top-hat windows, the theory curve, and the numbers
+    # test_sampling_error() prints (box.py:595-694, 770-782, 871-928)
+    out["sigma8"] = box.sigma8()
+    out["sigmaR20"] = box.sigmaR(20.)
+    kw = np.logspace(-2.5, 0.5, 32)
+    out["window_k"] = kw
+    out["window8"] = box.window(kw, 8.0 / standin.DEFAULT_COSMO['h'])
+    out["window1_8"] = box.window1(kw, 8.0 / standin.DEFAULT_COSMO['h'])
+    tk, tp = box.theoretical_power_spectrum()
+    out["theory_k"], out["theory_pk"] = tk[::25], tp[::25]
+    if N <= 256:
+        import contextlib
+        import io
+        import re
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            box.test_sampling_error()
+        nums = [float(x) for x in re.findall(r"(?:\t|= )\s*([-+0-9.eE]+|nan)\s*$", buf.getvalue(), flags=re.M)]
+        assert len(nums) == 9, buf.getvalue()
+        # s8_real, s8_th_win, s8_th_full, s8_realspace, ratio, s20_real, s20_realspace, ratio, std(delta)
+        out["sampling_report"] = np.array(nums)
     out["freq_array"] = box.freq_array()
     ax, ay = box.pixel_array(redshift=max(redshift, 0.5))
     out["pixel_x"], out["pixel_y"] = ax, ay
@@ -89,6 +110,7 @@ def capture(ref, name, N, box_scale, redshift, seed, s, what):
         out["pkln_k"], out["pkln_p"], out["pkln_e"] = box.binned_power_spectrum(delta_x=ln)
         out["tf_beam"] = probe(box.apply_transfer_fn(box.delta_k, standin.beam_highpass), s)
         out["tf_hp3"] = probe(box.apply_transfer_fn(box.delta_k, standin.highpass3), s)
+        out["tf_wedge"] = probe(box.apply_transfer_fn(box.delta_k, standin.wedge03), s)
         out["smooth8"] = probe(box.smooth_field(box.delta_k, 8.0), s)
         vel = box.realise_velocity()
         for c in range(3):
@@ -99,8 +121,12 @@ def capture(ref, name, N, box_scale, redshift, seed, s, what):
         out["rsd0"] = probe(box.redshift_space_density(delta_x=box.delta_x, velocity_z=vz, sigma_nl=0.), s)
         # stream position: 2 N^3 normals consumed so far; the next N^3 are the LOS noise
         out["rsd200"] = probe(box.redshift_space_density(delta_x=box.delta_x, velocity_z=vz, sigma_nl=200.), s)
-        out["pkrsd_k"], out["pkrsd_p"], out["pkrsd_e"] = box.binned_power_spectrum(
-            delta_x=box.redshift_space_density(delta_x=box.delta_x, velocity_z=vz, sigma_nl=0.))
+        rs = box.redshift_space_density(delta_x=box.delta_x, velocity_z=vz, sigma_nl=0.)
+        out["pkrsd_k"], out["pkrsd_p"], out["pkrsd_e"] = box.binned_power_spectrum(delta_x=rs)
+        # BASELINE configs[2]: wedge-filtered redshift-space field and its P(k)
+        fw = box.apply_transfer_fn(np.fft.fftn(rs), standin.wedge03)
+        out["rsd_wedge"] = probe(fw, s)
+        out["pkrsdw_k"], out["pkrsdw_p"], out["pkrsdw_e"] = box.binned_power_spectrum(delta_x=fw.real)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("wrote", name, "(%d arrays)" % len(out))
 

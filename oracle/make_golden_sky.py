@@ -57,6 +57,9 @@ def main():
             pca["cleaned%d" % nm] = cleaned
             pca["U%d" % nm] = U
             pca["amps%d" % nm] = amps
+            # fit_powerlaw=True (filters.py:146-154): modes projected out of d - (power-law fit of the mean spectrum)
+            cleaned, U, amps = filt.pca_filter(data, nmodes=nm, fit_powerlaw=True, return_filter=True)
+            pca["cleaned_pl%d" % nm], pca["U_pl%d" % nm], pca["amps_pl%d" % nm] = cleaned, U, amps
         pca["bandpass"] = filt.angular_bandpass_filter(data, 0.08, 0.3, d=1.)
         pca["bandpass_d2"] = filt.angular_bandpass_filter(data, 0.0, 0.11, d=2.)
         np.savez_compressed(os.path.join(OUT, name.replace("sky", "pca") + ".npz"), **pca)

@@ -2,7 +2,7 @@
 TEST INFRASTRUCTURE ONLY -- never imported by the product path.
 
 numpy restatement of the foreground-cleaning step of the reference's end-to-end flow:
-fastbox/filters.py mean_spectrum_filter (:35-56) and pca_filter (:93-183, fit_powerlaw=False).  Pinned against the
+fastbox/filters.py mean_spectrum_filter (:35-56) and pca_filter (:93-183, both settings of fit_powerlaw).  Pinned against the
 reference itself by oracle/make_golden_sky.py -> tests/golden/pca_*.npz (tests/test_oracle.py).
 """
 import numpy as np
@@ -23,9 +23,21 @@ def channel_covariance(field):
     return d_mean, x, np.cov(x)
 
 
-def pca_filter(field, nmodes, return_filter=False):
-    """filters.py:139-183 with fit_powerlaw=False."""
+def pca_filter(field, nmodes, fit_powerlaw=False, return_filter=False):
+    """filters.py:139-183.  fit_powerlaw: x = d - (power-law fit of the mean spectrum), :146-154; np.cov(x) centres
+    every channel on its own mean again, so the covariance is unchanged by the choice of what is subtracted."""
     d_mean, x, cov = channel_covariance(field)
+    if fit_powerlaw:
+        from scipy.optimize import curve_fit
+        d = field.reshape((-1, field.shape[-1])).T
+        freqs = np.linspace(1., 10., d.shape[0])
+
+        def fn(nu, amp, beta):
+            return amp * (nu / nu[0]) ** beta
+        pfit, _ = curve_fit(fn, freqs, d_mean.flatten(), p0=[d_mean[0][0], -2.7])
+        d_mean = fn(freqs, pfit[0], pfit[1])[:, np.newaxis]
+        x = d - d_mean
+        cov = np.cov(x)
     eigvals, eigvecs = np.linalg.eig(cov)
     idxs = np.argsort(eigvals)[::-1]
     eigvals = eigvals[idxs]

@@ -36,3 +36,9 @@ def beam_highpass(k_perp, k_par):
 def highpass3(kperp, kpar):
     """examples/example_endtoend.py:133."""
     return 1. - np.exp(-0.5 * (np.abs(kpar) / 0.009) ** 3.)
+
+
+def wedge03(k_perp, k_par):
+    """Foreground-wedge cut of BASELINE.json configs[2] (ours; the reference has no wedge filter, only user callables):
+    0 where |k_par| < 0.3 k_perp, else 1 -- fastbox_amd.Wedge(slope=0.3) as a reference-style callable."""
+    return np.where(np.abs(k_par) < 0.3 * k_perp, 0., 1.)

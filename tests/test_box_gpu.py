@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 
 FIELD_TOL = {"f32": 2e-5, "f64": 1e-11}
 PK_TOL = {"f32": 1e-5, "f64": 1e-11}
-CASES_ALL = ["n16_cube", "n16_cuboid", "n32_l1000", "n64_l1000"]
-CASES_PK = ["n64_l100", "n64_l4000", "n128_l1000", "n256_l1000"]
+CASES_ALL = ["n16_cube", "n16_cuboid", "n32_l1000", "n64_l1000", "n256_l1000"]
+CASES_PK = ["n64_l100", "n64_l4000", "n128_l1000"]
 
 
 def _load(golden_dir, name):
@@ -83,6 +83,23 @@ def test_density_and_power_spectrum(golden_dir, name, precision):
     assert np.array_equal(box.freq_array(), g["freq_array"])
     ax, ay = box.pixel_array(redshift=max(float(g["redshift"]), 0.5))
     assert np.array_equal(ax, g["pixel_x"]) and np.array_equal(ay, g["pixel_y"])
+    # sigma_R of the realisation (Simpson over the binned spectrum), the top-hat windows, the theory curve and the
+    # numbers test_sampling_error() prints, against what the reference produced (box.py:595-694, 770-782, 871-928)
+    rt = 2e-5 if precision == "f32" else 1e-10
+    assert np.isclose(box.sigma8(), float(g["sigma8"]), rtol=rt) and np.isclose(box.sigmaR(20.), float(g["sigmaR20"]), rtol=rt)
+    assert np.array_equal(box.window(g["window_k"], 8. / box.cosmo['h']), g["window8"])
+    assert np.array_equal(box.window1(g["window_k"], 8. / box.cosmo['h']), g["window1_8"])
+    tk, tp = box.theoretical_power_spectrum()
+    assert np.array_equal(tk[::25], g["theory_k"]) and np.array_equal(tp[::25], g["theory_pk"])
+    if "sampling_report" in g.files:
+        import contextlib
+        import io
+        import re
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            box.test_sampling_error()
+        nums = np.array([float(x) for x in re.findall(r"(?:\t|= )\s*([-+0-9.eE]+|nan)\s*$", buf.getvalue(), flags=re.M)])
+        assert nums.size == 9 and np.allclose(nums, g["sampling_report"], rtol=5e-5 if precision == "f32" else 1e-9)
 
 
 @pytest.mark.parametrize("precision", ["f32", "f64"])
@@ -108,6 +125,9 @@ def test_derived_fields(golden_dir, name, precision):
         assert _field_close(p(out), g["tf_beam"], 5 * ftol)
     for fn in (standin.highpass3, BeamHighpass(kpar0=0.009, power=3.)):
         assert _field_close(p(box.apply_transfer_fn(box.delta_k, fn)), g["tf_hp3"], 5 * ftol)
+    from fastbox_amd import Wedge
+    for fn in (standin.wedge03, Wedge(slope=0.3)):                # BASELINE configs[2]'s filter
+        assert _field_close(p(box.apply_transfer_fn(box.delta_k, fn)), g["tf_wedge"], 5 * ftol)
     assert _field_close(p(box.smooth_field(box.delta_k, 8.0)), g["smooth8"], 5 * ftol)
 
     vel = box.realise_velocity()
@@ -135,6 +155,13 @@ def test_redshift_space_fp64(golden_dir, name):
     assert _field_close(p(rsd200), g["rsd200"], 1e-9)
     kc, pk, err = box.binned_power_spectrum(delta_x=rsd0)
     assert _pk_close((pk,), (g["pkrsd_p"],), 1e-9)
+    # BASELINE configs[2]: the wedge-filtered redshift-space field and its P(k), fused route (filter and binning inside
+    # the forward transform's last pass) against the reference's ifftn / fftn sequence
+    from fastbox_amd import Wedge
+    filt = box.apply_transfer_fn(box.to_k(rsd0), Wedge(slope=0.3))
+    kc, pk, err = box.binned_power_spectrum(delta_x=filt.real)
+    assert np.array_equal(kc, g["pkrsdw_k"]) and _pk_close((pk, err), (g["pkrsdw_p"], g["pkrsdw_e"]), 1e-9)
+    assert _field_close(p(filt), g["rsd_wedge"], 1e-9)
 
 
 @pytest.mark.parametrize("N,vscale", [(128, 0.), (128, 40.), (256, 3e4)])
@@ -420,7 +447,7 @@ def test_benchmarked_chain_at_512_against_host_model():
     kc_g, pk_g, err_g = p_g.result()
     got = np.asarray(dx)
     geo = bo.box_geometry(L, N)
-    z = rng.half_spectrum_noise(N, seed, 0, np.float32)
+    z = rng.half_spectrum_noise(N, seed, 0)                 # double precision: what the fp32 device values approximate
     k = bo.k_magnitude(geo)[:, :, :N // 2 + 1]
     pk = np.nan_to_num(standin.pk_fn(standin.cosmology(), 1.0)(k.flatten())).reshape(k.shape)
     z *= np.sqrt(pk * geo["boxfactor"])

@@ -8,8 +8,8 @@ import pytest
 from oracle import box_oracle as bo
 from oracle import standin
 
-CASES_ALL = ["n16_cube", "n16_cuboid", "n32_l1000", "n64_l1000"]
-CASES_PK = ["n64_l100", "n64_l4000", "n128_l1000", "n256_l1000"]
+CASES_ALL = ["n16_cube", "n16_cuboid", "n32_l1000", "n64_l1000", "n256_l1000"]
+CASES_PK = ["n64_l100", "n64_l4000", "n128_l1000"]
 
 
 def _load(golden_dir, name):
@@ -57,6 +57,16 @@ def test_geometry_density_pk(golden_dir, name):
     assert _same(np.array(bo.parseval(dx, dk)), g["parseval"])
     Hz = standin.hubble(cosmo, a)
     assert _same(bo.freq_array(geo, a, 1420.405752, Hz), g["freq_array"])
+    # sigma_R from the realisation, the top-hat windows, the theory curve, test_sampling_error's numbers
+    h = cosmo['h']
+    assert bo.sigma_R(geo, dk, 8., h) == float(g["sigma8"]) and bo.sigma_R(geo, dk, 20., h) == float(g["sigmaR20"])
+    assert _same(bo.tophat_window(g["window_k"], 8. / h), g["window8"])
+    assert _same(bo.tophat_window1(g["window_k"], 8. / h), g["window1_8"])
+    tk = np.logspace(-3.5, 1., int(1e3))
+    assert _same(tk[::25], g["theory_k"]) and _same(standin.pk_fn(cosmo, a)(tk)[::25], g["theory_pk"])
+    if "sampling_report" in g.files:
+        rep = bo.sampling_report(geo, dx, dk, standin.pk_fn(cosmo, a), h)
+        assert np.allclose(rep, g["sampling_report"], rtol=1e-12, atol=0)     # (parsed from 17-digit prints)
 
 
 @pytest.mark.parametrize("name", CASES_ALL)
@@ -71,6 +81,7 @@ def test_derived_fields(golden_dir, name):
     assert _same(pk, g["pkln_p"]) and _same(err, g["pkln_e"])
     assert _same(p(bo.apply_transfer_fn(geo, dk, standin.beam_highpass)), g["tf_beam"])
     assert _same(p(bo.apply_transfer_fn(geo, dk, standin.highpass3)), g["tf_hp3"])
+    assert _same(p(bo.apply_transfer_fn(geo, dk, standin.wedge03)), g["tf_wedge"])
     assert _same(p(bo.smooth_field(geo, dk, 8.0, cosmo['h'])), g["smooth8"])
     vel = bo.realise_velocity(geo, dk, standin.velocity_fac(cosmo, a))
     for c in range(3):
@@ -84,6 +95,11 @@ def test_derived_fields(golden_dir, name):
     assert _same(p(bo.redshift_space_density(geo, dx, vz, Hz, 200., rng)), g["rsd200"])
     kc, pk, err = bo.binned_power_spectrum(geo, np.fft.fftn(rsd0))
     assert _same(pk, g["pkrsd_p"])
+    # BASELINE configs[2]: wedge-filtered redshift-space field and its P(k)
+    fw = bo.apply_transfer_fn(geo, np.fft.fftn(rsd0), standin.wedge03)
+    assert _same(p(fw), g["rsd_wedge"])
+    kc, pk, err = bo.binned_power_spectrum(geo, np.fft.fftn(fw.real))
+    assert _same(kc, g["pkrsdw_k"]) and _same(pk, g["pkrsdw_p"]) and _same(err, g["pkrsdw_e"])
 
 
 @pytest.mark.skipif(os.environ.get("FASTBOX_SLOW_TESTS", "0") != "1",
@@ -171,6 +187,8 @@ def test_pca_oracle_reproduces_reference_vectors(golden_dir, name):
     for nm in (2, 4):
         cleaned, U, amps = po.pca_filter(data, nm, return_filter=True)
         assert _same(cleaned, g["cleaned%d" % nm]) and _same(U, g["U%d" % nm]) and _same(amps, g["amps%d" % nm])
+        cpl, Upl, apl = po.pca_filter(data, nm, fit_powerlaw=True, return_filter=True)
+        assert _same(cpl, g["cleaned_pl%d" % nm]) and _same(Upl, g["U_pl%d" % nm]) and _same(apl, g["amps_pl%d" % nm])
         # what the device path is held to: the cleaned cube only depends on the span of the leading modes
         _, x, cov = po.channel_covariance(data)
         w, v = np.linalg.eigh(cov)

@@ -126,6 +126,15 @@ def test_pca_filter_matches_reference_vectors(golden_dir, name, precision, tol):
         assert np.max(np.abs(amps * sgn[:, None] - ref_amps)) < (2e-3 if precision == "f32" else 1e-9) * np.max(np.abs(ref_amps))
         only = filters.pca_filter(data, nm, box=box)                       # host array in, no filter returned
         assert np.max(np.abs(np.asarray(only) - g["cleaned%d" % nm])) < tol * scale
+        # fit_powerlaw=True: the modes come from the covariance about the TRUE channel means (np.cov re-centres),
+        # only the subtracted / restored spectrum is the power-law fit (filters.py:146-158)
+        cleaned, U, amps = filters.pca_filter(cube, nm, fit_powerlaw=True, return_filter=True)
+        assert np.max(np.abs(np.asarray(cleaned) - g["cleaned_pl%d" % nm])) < tol * scale
+        Ur = g["U_pl%d" % nm].real
+        assert np.max(np.abs(U @ U.T - Ur @ Ur.T)) < (1e-3 if precision == "f32" else 1e-9)
+        sgn = np.sign(np.sum(U * Ur, axis=0))
+        ref_amps = g["amps_pl%d" % nm].real
+        assert np.max(np.abs(amps * sgn[:, None] - ref_amps)) < (2e-3 if precision == "f32" else 1e-9) * np.max(np.abs(ref_amps))
 
 
 def test_channel_covariance_on_the_matrix_cores_full_size():

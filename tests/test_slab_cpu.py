@@ -69,6 +69,45 @@ def test_slab_driver_gloo(tmp_path, world):
             assert np.allclose(a, b, rtol=1e-10, atol=0, equal_nan=True)
 
 
+def _mc_worker(rank, world, port, out_dir):
+    """Monte-Carlo steps, synchronous and pipelined (wait=False: three realisations in flight, asynchronous
+    all-to-alls overlapping the other realisations' passes), on the same seeds."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fastbox_amd.distributed import SlabBox
+        from tests.slab_numpy_ops import NumpySlabOps
+        mk = lambda: SlabBox(standin.DEFAULT_COSMO, box_scale=L, nsamp=N, seed=SEED,
+                             ops_factory=lambda g, P, r: NumpySlabOps(g, P, r),
+                             pk_fn=standin.pk_fn(standin.cosmology(), 1.0))
+        a, b = mk(), mk()
+        sync = [a.realise_and_power(nbins=12, lognormal=(i % 2 == 1)) for i in range(7)]
+        tickets = [b.realise_and_power(nbins=12, lognormal=(i % 2 == 1), wait=False) for i in range(7)]
+        early = tickets[2].result()                  # resolving a ticket in the middle drains the pipeline
+        more = [b.realise_and_power(nbins=12, wait=False) for _ in range(2)]
+        b.flush()
+        piped = [t.result() for t in tickets]
+        assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(early, piped[2]))
+        tail = [a.realise_and_power(nbins=12) for _ in range(2)]
+        np.savez(os.path.join(out_dir, "mc%d.npz" % rank), sync=np.array(sync), piped=np.array(piped),
+                 tail=np.array(tail), more=np.array([t.result() for t in more]),
+                 dx_sync=a.delta_x.numpy().copy(), dx_piped=b.delta_x.numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_pipelined_monte_carlo_equals_synchronous_steps(tmp_path, world):
+    mp.spawn(_mc_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        g = np.load(os.path.join(str(tmp_path), "mc%d.npz" % r))
+        assert np.array_equal(g["sync"], g["piped"], equal_nan=True)          # same kernels, same order of sums
+        assert np.array_equal(g["tail"], g["more"], equal_nan=True)
+        assert np.array_equal(g["dx_sync"], g["dx_piped"])                     # both hold the last realisation's slab
+    g0 = np.load(os.path.join(str(tmp_path), "mc0.npz"))
+    assert not np.array_equal(g0["sync"][0], g0["sync"][2], equal_nan=True)    # different realisations
+
+
 def test_shell_thresholds_reproduce_digitize():
     """Host tables handed to the device: the threshold form equals np.digitize on every shell
     that is not flagged ambiguous, for several box sizes (edge-on-a-shell cases included)."""

@@ -4,8 +4,8 @@
 #   bash tools/knockout.sh > gpurun_out/knockout.txt
 set -e
 BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"
-for V in ${KNOCKOUT_VARIANTS:-"" "-DFB_EXPERIMENT_NOAMP" "-DFB_EXPERIMENT_NOBM" "-DFB_THREEFRY_ROUNDS=4" \
-         "-DFB_EXPERIMENT_NOAMP@-DFB_EXPERIMENT_NOBM@-DFB_THREEFRY_ROUNDS=4"}; do
+for V in ${KNOCKOUT_VARIANTS:-"" "-DFB_EXPERIMENT_NOAMP" "-DFB_EXPERIMENT_NOBM" "-DFB_PHILOX_ROUNDS=1" \
+         "-DFB_EXPERIMENT_NOAMP@-DFB_EXPERIMENT_NOBM@-DFB_PHILOX_ROUNDS=1"}; do
     V="${V//@/ }"
     make -C fastbox_amd/csrc clean > /dev/null
     make -C fastbox_amd/csrc -j16 CXXFLAGS="$BASE $V" > /dev/null 2>&1
