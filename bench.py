@@ -64,6 +64,12 @@ def parse(argv=None):
                          "all-to-all per transform (strong scaling)")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent realisations are issued round-robin on this many HIP streams (boxes)")
+    ap.add_argument("--sizes", default="256,1024,2048", help="N = 1: other grid sizes of the `sizes` leg")
+    ap.add_argument("--slab-sizes", default="1024,2048", help="N > 1: grid sizes of the `strong_scaling` leg")
+    ap.add_argument("--spin-up", type=float, default=0.15,
+                    help="seconds of untimed steps of the same workload run directly before the warm-up steps: the GPU "
+                         "raises its clocks over ~50 ms of load (tools/step_timeline.py: the first 20 steps after an idle "
+                         "gap run 10 %% below the sustained rate), and the metric is the sustained rate")
     ap.add_argument("--plane-batch", type=int, default=None,
                     help="x-planes per cache-resident batch of the y/z passes (default: the library's size for one box per "
                          "GPU when --streams 1, N/8 when several boxes share the GPU)")
@@ -348,15 +354,34 @@ def main():
         if world == 1:
             def sizes():
                 out = {}
-                for n2, st in ((256, 100), (1024, 8), (2048, 3)):
+                for n2 in [int(x) for x in args.sizes.split(",") if x]:
                     if n2 != N:
+                        st = max(3, min(100, int(100 * (256. / n2) ** 3)))
                         out[str(n2)] = quick_rate(args, n2, args.precision, st, 2, rank, local_rank, torch)
                 return out
             guarded("sizes", sizes)
-    _warm(step, max(args.warmup, len(boxes)))
-    fence()
     in_region = nstreams == 1             # event brackets inside the timed region only when kernels run alone
     ev_stride = 1 if args.all_kernel_events else max(1, args.kernel_event_stride)
+    prof_steps = args.steps
+    if not in_region:
+        # kernels of different boxes overlap in the timed region, so the roofline kernel is timed on its own here, on
+        # ONE stream, directly before the warm-up steps (this pass also leaves the GPU at its sustained clocks)
+        prof_steps = 40
+        one = _step_fn(boxes[:1], args.nbins)
+        one().result()
+        torch.cuda.synchronize()
+        eng.profile_start(["fft_strided"], stride=1)
+        for p in [one() for _ in range(prof_steps)]:
+            p.result()
+        prof = eng.profile_stop()
+        plain_launches = prof["fft_strided"][1]
+    t_spin = time.perf_counter()
+    spin_steps = 0
+    while time.perf_counter() - t_spin < args.spin_up:
+        _warm(step, 10)
+        spin_steps += 10
+    _warm(step, max(args.warmup, len(boxes)))
+    fence()
     if in_region:
         eng.profile_start(None if args.all_kernel_events else ["fft_strided"], stride=ev_stride)
     t0 = time.perf_counter()
@@ -381,21 +406,10 @@ def main():
 
     # ---------------------------------------------------------------- rank 0: the line
     s = 4 if args.precision == "f32" else 8
-    prof_steps = args.steps
     timed_in = "timed region (every %d%s launch bracketed)" % (ev_stride, "th" if ev_stride > 1 else "st")
     if not in_region:
-        # kernels of different boxes overlapped in the timed region: time the roofline kernel on its own, one stream
-        prof_steps = min(max(args.steps, 10), 40)
-        one = _step_fn(boxes[:1], args.nbins)
-        one().result()
-        torch.cuda.synchronize()
-        eng.profile_start(["fft_strided"], stride=1)
-        for p in [one() for _ in range(prof_steps)]:
-            p.result()
-        prof = eng.profile_stop()
-        plain_launches = prof["fft_strided"][1]
-        timed_in = "separate pass of %d steps on ONE stream right after the timed region (in the region itself kernels " \
-                   "of %d boxes share the chip); every launch bracketed" % (prof_steps, nstreams)
+        timed_in = "separate pass of %d steps on ONE stream directly before the warm-up steps (in the timed region itself " \
+                   "kernels of %d boxes share the chip); every launch bracketed" % (prof_steps, nstreams)
     ms, launches = prof["fft_strided"]
     # a step holds two strided y passes (inverse and forward), each launched once per x-plane batch (fb_fft_launch.inc
     # yz_passes): one launch reads and writes its share of N*N*(N/2) complex values (packed work spectrum)
@@ -411,7 +425,8 @@ def main():
         "config": {"workload": "%d^3 Gaussian box (device Philox4x32-10 noise, stand-in EH P(k), L=1000 Mpc) + "
                                "log-normal transform + binned P(k), nbins=%d" % (N, args.nbins),
                    "nsamp": N, "parallelism": "replicas x%d" % world, "streams_per_gpu": len(boxes),
-                   "warmup_steps_run": max(args.warmup, len(boxes))},
+                   "warmup_steps_run": max(args.warmup, len(boxes)), "spin_up_s": args.spin_up,
+                   "spin_up_steps": spin_steps},
         "roofline": {"bound": "hbm", "kernel": "k_fft_strided (y FFT pass over a plane batch of the half spectrum)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if achieved else None,
@@ -447,7 +462,8 @@ def main():
         # one box over all ranks, as child jobs (the other ranks of this job have left their GPUs by now)
         out = {}
         torch.cuda.empty_cache()
-        for n2, st in ((1024, 10), (2048, 5)):
+        for n2 in [int(x) for x in args.slab_sizes.split(",") if x]:
+            st = 10 if n2 <= 1024 else 5
             try:
                 rc, txt = spawn_ranks(world, ["--mode", "slab", "--nsamp", str(n2), "--steps", str(st), "--warmup", "2",
                                               "--gpus", str(world), "--precision", args.precision], timeout=420)

@@ -12,6 +12,7 @@ from .transfer import BeamHighpass, Wedge         # noqa: F401
 from .device import DeviceArray                   # noqa: F401
 from .sky import ForegroundModel, NoiseModel      # noqa: F401
 from . import filters                             # noqa: F401
+from . import montecarlo                          # noqa: F401
 from .beams import BeamModel                      # noqa: F401
 
 __version__ = "0.1.0"

@@ -9,13 +9,15 @@ turn into float64 / complex128 ndarrays when numpy touches them.  Additive,
 reference-preserving keyword arguments: ``precision`` ('f32' storage with fp64
 bin sums, or 'f64'), ``rng`` ('numpy' = the reference's legacy global stream,
 drawn on the host and uploaded -- same seed, same field; 'device' = on-device
-counter-based Threefry4x32-20 RNG for throughput, reproducible on the host with
+counter-based Philox4x32-10 RNG for throughput, reproducible on the host with
 ``fastbox_amd.rng``), ``seed``, ``device``, ``stream``.
 
 No CPU fallback exists: without the HIP library or a GPU every compute method
 raises.
 """
 import numpy as np
+
+from . import hostgeom
 
 from . import cosmology as _builtin_cosmology
 from . import device as _dev
@@ -40,15 +42,15 @@ except Exception:                           # pragma: no cover
     from scipy.integrate import simps as _simpson
 
 
-def _finish_bins(cnt, s1, s2, boxfactor):
+def _finish_bins(cnt, s1, s2, boxfactor, eps=0.):
     """(mean, std/sqrt(n)) per bin from (count, sum |dk|^2, sum |dk|^4), bin 0 dropped
-    (box.py:761-768).  The variance form is exactly 0 for a bin whose modes all carry the
-    same |delta_k|^2 (a mirrored pair), as np.std gives; empty bins are NaN."""
-    with np.errstate(all="ignore"):
-        vals = s1 / (cnt * boxfactor)
-        var = (s2 - s1 * s1 / cnt) / cnt
-        stddev = np.sqrt(np.maximum(var, 0.)) / boxfactor / np.sqrt(cnt)
-    return np.array(vals[1:]), np.array(stddev[1:])
+    (box.py:761-768); see hostgeom.finish_bins."""
+    return hostgeom.finish_bins(cnt, s1, s2, boxfactor, eps)
+
+
+def _eps_of(engine):
+    """rounding unit of the plan's |delta_k|^2 values: the precision floor of the variance form"""
+    return 2. ** -23 if engine.precision == "f32" else 2. ** -52
 
 
 class _Ready(object):
@@ -75,7 +77,7 @@ class PendingSpectrum(object):
             if self._lnv:                      # transform of exp(d): rescale to exp(d)/mean - 1
                 mean = esum / self._lnv
                 s1, s2 = s1 / mean ** 2, s2 / mean ** 4
-            self._out = (self._kc,) + _finish_bins(self._cnt, s1, s2, self._bf)
+            self._out = (self._kc,) + _finish_bins(self._cnt, s1, s2, self._bf, _eps_of(self._eng))
             self._res = self._keep = None
         return self._out
 
@@ -329,7 +331,9 @@ class CosmoBox(object):
                 n2 = np.arange(3 * (N // 2) ** 2 + 1, dtype=np.float64)
                 k = 2. * np.pi * np.sqrt(n2) / self.Lx
                 pk = np.nan_to_num(np.asarray(self._power(k, scale_factor, linear), dtype=np.float64))
-                self.engine.set_amplitude_shells(np.sqrt(pk * self.boxfactor))
+                amp = np.sqrt(pk * self.boxfactor)
+                self.engine.set_amplitude_shells(amp)
+                self._sigma2 = hostgeom.field_variance_cubic(N, amp)       # variance of the fields drawn from it
             else:
                 # |k| depends on the mode numbers only through |m_x|, |m_y|, |m_z|: evaluate P(k) on the
                 # (N/2+1)^3 magnitudes (an eighth of the stored modes), in the reference's operation order
@@ -338,7 +342,9 @@ class CosmoBox(object):
                 s = (a[:M, None, None] + a[N:N + M][None, :, None]) + a[2 * N:2 * N + M][None, None, :]
                 k = 2. * np.pi * np.sqrt(s)
                 pk = np.nan_to_num(np.asarray(self._power(k.flatten(), scale_factor, linear), dtype=np.float64))
-                self.engine.set_amplitude_sym(np.sqrt(pk.reshape(k.shape) * self.boxfactor))
+                amp = np.sqrt(pk.reshape(k.shape) * self.boxfactor)
+                self.engine.set_amplitude_sym(amp)
+                self._sigma2 = hostgeom.field_variance_sym(N, amp)
         self._amp_key = key
 
     def realise_density(self, linear=False, redshift=None, inplace=True):
@@ -575,7 +581,7 @@ class CosmoBox(object):
                 cnt, s1, s2 = eng.bin_power(root._filtered)
             else:
                 cnt, s1, s2 = eng.bin_power(src, filt=filt)
-            out = (kc,) + _finish_bins(cnt, s1, s2, self.boxfactor)
+            out = (kc,) + _finish_bins(cnt, s1, s2, self.boxfactor, _eps_of(eng))
             return out if wait else _Ready(out)
 
         if delta_x is None and delta_k is None and thr is not None and self._delta_k is None \
@@ -587,11 +593,15 @@ class CosmoBox(object):
             # fused path (cubic boxes): r2c with the binning inside the last pass
             ln = isinstance(delta_x, LognormalField) and not delta_x.materialised and bins[0] > 0.
             src = delta_x.source if ln else self._as_real(delta_x)
+            # log-normal of this box's own realisation: exp(d - sigma^2/2) instead of exp(d) -- the estimate
+            # exp(d)/<exp(d)> - 1 is the same, and a single-precision plan's sums stay finite for sigma ~ 8
+            # (a non-linear P(k) sampled at 2 Mpc: exp(d) reaches 1e19, |delta_k|^4 would overflow)
+            shift = 0.5 * getattr(self, "_sigma2", 0.0) if (ln and src is getattr(self, "delta_x", None)) else 0.0
             if isinstance(src, PendingDensity) and not src.materialised:
-                res, real = eng.power_pending(src._pending, pre_exp=ln)     # z passes fused
+                res, real = eng.power_pending(src._pending, pre_exp=ln, exp_shift=shift)     # z passes fused
                 src._adopt(real)
             else:
-                res, _ = eng.power_fused(src, pre_exp=ln)
+                res, _ = eng.power_fused(src, pre_exp=ln, exp_shift=shift)
             pending = PendingSpectrum(eng, res, bins.size, kc, self.boxfactor, self.N ** 3 if ln else None, None)
             return pending if not wait else pending.result()
 
@@ -602,7 +612,7 @@ class CosmoBox(object):
         else:
             spec = self._as_spectrum(delta_k)
         cnt, s1, s2 = eng.bin_power(spec)
-        out = (kc,) + _finish_bins(cnt, s1, s2, self.boxfactor)
+        out = (kc,) + _finish_bins(cnt, s1, s2, self.boxfactor, _eps_of(eng))
         return out if wait else _Ready(out)
 
     def sigmaR(self, R):

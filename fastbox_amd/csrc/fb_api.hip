@@ -605,6 +605,12 @@ int fb_set_tuning(fb_plan* p, int stagger_plain, int stagger_gen, int stagger_bi
     p->stagger[0] = stagger_plain; p->stagger[1] = stagger_gen; p->stagger[2] = stagger_bin;
     return FB_OK;
 }
+int fb_set_exp_shift(fb_plan* p, double shift) {
+    FB_REQUIRE(p, "null pointer");
+    FB_REQUIRE(shift == shift && shift > -1e4 && shift < 1e4, "shift out of range");
+    p->exp_shift = shift;
+    return FB_OK;
+}
 int fb_set_plane_batching(fb_plan* p, int planes, int streams) {
     FB_REQUIRE(p, "null pointer");
     FB_REQUIRE(planes >= -1 && streams >= 0 && streams <= 2, "planes >= -1 (auto), streams 0 (auto), 1 or 2");

@@ -133,8 +133,8 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     TileLayout<T, TZ> lay{tile, c};
 #ifdef FB_STAMPS      // diagnostic build only: phase time stamps of every workgroup (tools/stamps.py)
     long long* stamp = (smode_bins(MODE))
-        ? reinterpret_cast<long long*>(op.partial + (size_t)2 * op.nbins * op.partial_stride) + (size_t)blockIdx.x * 8
-        : reinterpret_cast<long long*>(const_cast<double*>(op.bins)) + (size_t)blockIdx.x * 8;
+        ? reinterpret_cast<long long*>(op.partial + (size_t)2 * op.nbins * op.partial_stride) + (size_t)blockIdx.x * 32
+        : reinterpret_cast<long long*>(const_cast<double*>(op.bins)) + (size_t)blockIdx.x * 32;
     const bool stamp_ok = (smode_bins(MODE)) ? (op.partial != nullptr) : (op.bins != nullptr);
 #define FB_STAMP(k) do { if (tid == 0 && stamp_ok) stamp[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     FB_STAMP(0);
@@ -161,6 +161,22 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     [[maybe_unused]] cx<T> vn[E];
     [[maybe_unused]] int wb_lo = 0, wb_hi = 0, wb_edge = 0x7fffffff;   // BIN: this wave's bins (see epilogue)
     [[maybe_unused]] bool wb_ok = false, wb_rng = false;
+    // BIN: lane l keeps thresholds l, l + 64, ... (FB_MAX_BINS = 256: four registers), fetched before the tile so that
+    // one memory latency covers both; "number of thresholds <= n^2" is then a compare and a ballot per 64 thresholds
+    // instead of a binary search of dependent scalar loads (5.8 k of a workgroup's 20 k cycles, tools/stamps.py)
+    [[maybe_unused]] int thrv[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    if constexpr (smode_bins(MODE)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r * 64 < op.nbins) { const int q = r * 64 + (tid & 63); thrv[r] = q < op.nbins ? op.thr[q] : 0x7fffffff; }
+    }
+    [[maybe_unused]] auto wave_bin = [&](int n2) -> int {          // n2 wave-uniform
+        int b = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r * 64 < op.nbins) b += __builtin_popcountll(__ballot(thrv[r] <= n2));
+        return b;
+    };
     int tile_id = blockIdx.x;
     if constexpr (MODE != SMODE_GEN && PERSIST == 1) {          // the launcher guarantees gridDim.x <= ntiles
         const int bx0 = tile_id % a.ntx;
@@ -389,8 +405,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         else load_tables();
         if constexpr (smode_bins(MODE) && (64 * E) % TZ == 0 && (N / 2) % ((64 * E) / TZ) == 0 && TZ % E == 0) {
             // The bins of this wave's block of the tile depend on the tile's coordinates only: look
-            // them up now, with scalar loads from the global threshold table, while the tile's data
-            // is still on its way from HBM.
+            // them up now, while the tile's data is still on its way from HBM.
             constexpr int RW = (64 * E) / TZ;
             const int r0 = __builtin_amdgcn_readfirstlane((tid >> 6) * RW);
             const int ma = mode_of(r0, N), mb = mode_of(r0 + RW - 1, N);
@@ -399,13 +414,18 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             const int kzhi = (bx * TZ + TZ - 1 < a.ncols - 1) ? bx * TZ + TZ - 1 : a.ncols - 1;
             const int wlo = (a2 < b2 ? a2 : b2) + myy * myy + bx * TZ * bx * TZ;
             const int whi = (a2 > b2 ? a2 : b2) + myy * myy + kzhi * kzhi;
-            wb_lo = __builtin_amdgcn_readfirstlane(shell_bin(op.thr, op.nbins, wlo));
-            wb_hi = __builtin_amdgcn_readfirstlane(shell_bin(op.thr, op.nbins, whi));
+            wb_lo = wave_bin(wlo);
+            wb_hi = wave_bin(whi);
             bool hit = false;
             for (int z = 0; z < op.namb; ++z) hit |= (op.amb[z] >= wlo && op.amb[z] <= whi);
             wb_rng = hit;                          // an edge-shell lies in the wave's n^2 RANGE: look closer below
             wb_ok = wb_hi - wb_lo <= 1;
-            wb_edge = (wb_ok && wb_hi > wb_lo) ? op.thr[wb_lo] : 0x7fffffff;       // first n^2 of bin wb_hi
+            wb_edge = 0x7fffffff;                   // first n^2 of bin wb_hi = thr[wb_lo], from the lane that holds it
+            if (wb_ok && wb_hi > wb_lo) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((wb_lo >> 6) == r) wb_edge = __builtin_amdgcn_readlane(thrv[r], wb_lo & 63);
+            }
         }
         FB_STAMP(3);
         if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
@@ -581,6 +601,9 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         tile_id += gridDim.x;
     } while (tile_id < a.ntiles);
     if constexpr (smode_bins(MODE)) {
+#ifdef FB_STAMPS
+        if ((tid & 63) == 0 && stamp_ok) stamp[8 + (tid >> 6)] = (long long)__builtin_amdgcn_s_memtime();   // this wave's binning is done
+#endif
         __syncthreads();
         const int nb = op.nbins;
         for (int i = tid; i < 2 * nb; i += NT) {          // partial[value][workgroup]
@@ -687,6 +710,7 @@ template <typename T> struct ContigArgs {
     double* exp_partial;    // r2c + pre_exp: [gridDim.x] block sums of exp(x)
     void* out2;             // C2R2C: half spectrum out (may alias `in`), pitch/skip as `in`
     int packed;             // half spectrum rows hold k_z = 0 .. N/2-1, element 0 = X[0] + i X[N/2] (both are real for a real line)
+    T exp_shift;            // pre_exp: transform exp(x - exp_shift) (fb_set_exp_shift: keeps a high-variance field's sums in range)
 };
 
 template <int NF> constexpr int contig_lines() {   // lines per workgroup
@@ -726,6 +750,8 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
         // Z[k] = (X[k] + conj X[n-k]) + i e^{+2 pi i k/N} (X[k] - conj X[n-k]); the
         // imaginary parts of X[0], X[n] are dropped (Hermitian projection).
         const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in) + (line + (a.in_skip ? line / a.in_skip : 0)) * a.in_pitch;
+        // (taking the untangle twiddles straight from the global table, so that the line's own loads are not held behind
+        // this barrier, was measured slower: 0.3245 against 0.3062 ms per step for the fused z pass)
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -755,7 +781,7 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
         if (a.pre_exp) {
 #pragma unroll
             for (int e = 0; e < E; ++e)
-                if (valid) { v[e].x = fb_exp(v[e].x); v[e].y = fb_exp(v[e].y); esum += (double)v[e].x + (double)v[e].y; }
+                if (valid) { v[e].x = fb_exp(v[e].x - a.exp_shift); v[e].y = fb_exp(v[e].y - a.exp_shift); esum += (double)v[e].x + (double)v[e].y; }
         }
         if constexpr (MODE == ZMODE_R2C || !WAVE) __syncthreads();      // R2C: the twiddles; C2R2C: lines[] is this wave's own
         else exchange_sync<true>();

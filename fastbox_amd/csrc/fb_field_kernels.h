@@ -343,9 +343,16 @@ __device__ __forceinline__ T filter_value(const FilterSpec& f, const KGeom& g, i
         fb_sincos(x, &s, &c);
         return ((T)3 / (x * x * x)) * (s - x * c);
     }
+    if (f.kind == FILT_WEDGE) {
+        // a mask: decided in double on the tables numpy's own expression would see (k_par = 2 pi m / L_z, k_perp as
+        // box.py:374 forms it), product and sum rounded separately as numpy does -- modes exactly on the wedge's
+        // edge (|m_z| = slope * m_perp happens on integer grids) fall on the same side as in the reference
+#pragma clang fp contract(off)
+        const double edge = f.p[0] * kperp_row + f.p[1];
+        return (fabs(g.kpar[l]) < edge) ? (T)0 : (T)1;
+    }
     const T kperp = (T)kperp_row;
     const T kpar = (T)g.kpar[l];
-    if (f.kind == FILT_WEDGE) return (fabs(kpar) < (T)f.p[0] * kperp + (T)f.p[1]) ? (T)0 : (T)1;
     T v = (T)1;
     if (f.p[0] > 0) {
         const T r = fabs(kpar) / (T)f.p[0];

@@ -21,6 +21,7 @@ struct fb_plan {
     int debug_no_mem = 0;    // tuning aid (fb_debug_strided_pass mode >= 10)
     int plane_batch = -1;    // x-planes per batch of the y/z passes: -1 sized to the Infinity Cache, 0 whole box (fb_set_plane_batching)
     int plane_streams = 0;   // 1 | 2 streams for alternate batches; 0: by grid size
+    double exp_shift = 0.0;  // fused log-normal transforms use exp(x - exp_shift) (fb_set_exp_shift)
     int num_cu = 256;        // compute units of the device (persistent-grid sizing)
     int NZV = 0;             // stored k_z modes of a half spectrum: N/2+1
     int NZP = 0;             // row pitch of a half spectrum (complex elements)

@@ -317,6 +317,8 @@ class Engine(object):
 
     # -- FFTs -------------------------------------------------------------------
     def fft_r2c(self, real, pre_exp=False):
+        if pre_exp:
+            self._set_exp_shift(0.0)
         out = self.empty(HALF)
         _lib.call("fb_fft_r2c", self._plan, real.ptr, out.ptr, 1 if pre_exp else 0, self.stream)
         return out
@@ -486,17 +488,25 @@ class Engine(object):
         _lib.call("fb_realise_density_finish", self._plan, pend.ptr, out.ptr, self.stream)
         return out
 
-    def power_pending(self, pend, pre_exp=False):
-        """Fused z pass (writes delta_x) + P(k) of (exp of) it.  Returns (results buffer, delta_x)."""
+    def _set_exp_shift(self, shift):
+        if shift != getattr(self, "_exp_shift", 0.0):
+            _lib.call("fb_set_exp_shift", self._plan, float(shift))
+            self._exp_shift = float(shift)
+
+    def power_pending(self, pend, pre_exp=False, exp_shift=0.0):
+        """Fused z pass (writes delta_x) + P(k) of (exp of) it.  Returns (results buffer, delta_x).
+        exp_shift: the exponentials are formed as exp(x - exp_shift) (fb_set_exp_shift)."""
+        self._set_exp_shift(exp_shift if pre_exp else getattr(self, "_exp_shift", 0.0))
         res = self._result_slot()
         out = self.empty(REAL)
         _lib.call("fb_power_spectrum_pending", self._plan, pend.ptr, out.ptr, 1 if pre_exp else 0, res.ptr,
                   self.stream)
         return res, out
 
-    def power_fused(self, real, pre_exp=False, keep_spectrum=False):
+    def power_fused(self, real, pre_exp=False, keep_spectrum=False, exp_shift=0.0):
         """Asynchronous r2c + shell binning (cubic boxes).  Returns (results buffer, spectrum or None);
         results = [2*nbins+1] doubles on the device, fetched with `fetch_results`."""
+        self._set_exp_shift(exp_shift if pre_exp else getattr(self, "_exp_shift", 0.0))
         res = self._result_slot()
         work = self.empty(HALF) if keep_spectrum else self._scratch_half()
         _lib.call("fb_power_spectrum_device", self._plan, real.ptr, work.ptr, 1 if pre_exp else 0,

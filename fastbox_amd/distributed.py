@@ -88,6 +88,9 @@ class HipSlabOps(object):
     def set_bins(self, bins, thr, amb):
         self.engine.set_bins(bins, thr, amb)
 
+    def set_exp_shift(self, shift):
+        self.engine._set_exp_shift(shift)
+
     def bin_counts(self):
         return self.engine.bin_counts()
 
@@ -141,6 +144,7 @@ class SlabBox(object):
         if world is None:
             world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank, self.world = rank, world
+        self._eps = 2. ** -23 if (precision == "f32" and ops_factory is None) else 2. ** -52     # hostgeom.finish_bins
         self.g = hostgeom.grid(box_scale, nsamp)
         N = self.N = nsamp
         if not self.g["cubic"]:
@@ -160,7 +164,12 @@ class SlabBox(object):
             ops_factory = lambda g, P, r: HipSlabOps(g, P, r, precision=precision,
                                                      device=(r if device is None else device))
         self.ops = ops_factory(self.g, world, rank)
-        self.ops.set_amplitude(hostgeom.shell_amplitude(N, self.g["L"][0], self.boxfactor, pk_fn))
+        amp = hostgeom.shell_amplitude(N, self.g["L"][0], self.boxfactor, pk_fn)
+        self.ops.set_amplitude(amp)
+        # fused log-normal transforms form exp(d - sigma^2/2): same estimate, sums in range on single-precision plans
+        self._sigma2 = hostgeom.field_variance_cubic(N, amp)
+        if hasattr(self.ops, "set_exp_shift"):
+            self.ops.set_exp_shift(0.5 * self._sigma2)
         self._kslab = self.ops.new_kslab()
         self._xbuf = self.ops.new_kslab()          # same byte count as [P][N/P][N/P][pitch]
         self._half = self.ops.new_half_local()
@@ -396,7 +405,7 @@ class SlabBox(object):
         if lognormal:
             mean = esum / float(self.N) ** 3
             s1, s2 = s1 / mean ** 2, s2 / mean ** 4
-        return (kc,) + hostgeom.finish_bins(self.ops.bin_counts(), s1, s2, self.boxfactor)
+        return (kc,) + hostgeom.finish_bins(self.ops.bin_counts(), s1, s2, self.boxfactor, self._eps)
 
     def binned_power_spectrum(self, delta_x=None, nbins=20, kbins=None, lognormal=False):
         """P(k) of the distributed field (of its log-normal transform if ``lognormal``); every rank
@@ -436,7 +445,7 @@ class _Ticket(object):
         if self.lognormal:
             mean = esum / float(box.N) ** 3
             s1, s2 = s1 / mean ** 2, s2 / mean ** 4
-        return (self.kc,) + hostgeom.finish_bins(box.ops.bin_counts(), s1, s2, box.boxfactor)
+        return (self.kc,) + hostgeom.finish_bins(box.ops.bin_counts(), s1, s2, box.boxfactor, box._eps)
 
 
 class _Deferred(object):

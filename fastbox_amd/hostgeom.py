@@ -51,6 +51,31 @@ def shell_amplitude(N, Lside, boxfactor, pk_fn):
         return np.sqrt(pk * boxfactor)
 
 
+def shell_multiplicity(N):
+    """Number of modes (i, j, l) of the full (N, N, N) grid on every integer shell n^2 = i^2 + j^2 + l^2."""
+    m2 = (mode_numbers(N) ** 2).astype(np.int64)
+    h2 = np.bincount((m2[:, None] + m2[None, :]).ravel())            # pairs (i, j)
+    out = np.zeros(3 * (N // 2) ** 2 + 1, dtype=np.float64)
+    vals, cnt = np.unique(m2, return_counts=True)
+    for v, c in zip(vals, cnt):
+        out[v:v + h2.size] += c * h2
+    return out
+
+
+def field_variance_cubic(N, amp_shells):
+    """Variance of the realised field whose modes have E|delta_k|^2 = amp^2: sum_k amp_k^2 / N^6 (Parseval)."""
+    a = np.asarray(amp_shells, dtype=np.float64)
+    return float(np.sum(shell_multiplicity(N)[:a.size] * a * a) / float(N) ** 6)
+
+
+def field_variance_sym(N, amp_sym):
+    """The same from the (|m_x|, |m_y|, |m_z|) table of a box of any shape (N/2+1 entries per axis)."""
+    w = np.full(N // 2 + 1, 2.0)
+    w[0] = w[-1] = 1.0
+    a = np.asarray(amp_sym, dtype=np.float64)
+    return float(np.einsum("i,j,k,ijk->", w, w, w, a * a) / float(N) ** 6)
+
+
 def bin_edges(g, nbins=20, kbins=None):
     """Edges and the centres of bins 1..nbins-1 (box.py:745-751)."""
     if kbins is not None:
@@ -80,12 +105,17 @@ def shell_thresholds(N, Lside, bins):
     return thr.astype(np.int32), tuple(int(a) for a in amb)
 
 
-def finish_bins(cnt, s1, s2, boxfactor):
+def finish_bins(cnt, s1, s2, boxfactor, eps=0.):
     """(mean, std/sqrt(n)) per bin from (count, sum |dk|^2, sum |dk|^4), bin 0 dropped
-    (box.py:761-768); exactly 0 spread for single-valued bins, NaN for empty ones."""
+    (box.py:761-768); exactly 0 spread for single-valued bins (a mirrored pair of modes), as np.std gives, NaN for
+    empty ones.  ``eps``: rounding unit of the |dk|^2 values the sums were formed from (2^-23 for a single-precision
+    plan).  A variance below 4 eps mean^2 is rounding of the squares, not spread -- the form sum p^2 - (sum p)^2/n of
+    a single-valued bin leaves +-eps p^2, whose square root would read as a spread of 2e-4 -- and is reported as 0."""
     with np.errstate(all="ignore"):
         vals = s1 / (cnt * boxfactor)
         var = (s2 - s1 * s1 / cnt) / cnt
+        if eps:
+            var = np.where(var <= 4. * eps * (s1 / cnt) ** 2, 0., var)
         stddev = np.sqrt(np.maximum(var, 0.)) / boxfactor / np.sqrt(cnt)
     return np.array(vals[1:]), np.array(stddev[1:])
 

@@ -76,7 +76,7 @@ int fb_set_amplitude_sym(fb_plan* plan, const double* amp, int64_t n);
 int fb_set_amplitude_dense(fb_plan* plan, const void* amp_dev);
 /* parity mode: re, im are the reference's np.random.normal draws, T[N][N][N] on the device  */
 int fb_colour_noise(fb_plan* plan, const void* re, const void* im, void* half_out, void* stream);
-/* throughput mode: Threefry4x32-20 keyed by (seed, realisation), counter = mode index        */
+/* throughput mode: Philox4x32-10, key = seed, counter = (mode index, stream, realisation); fb_rng.h */
 int fb_colour_device(fb_plan* plan, uint64_t seed, uint64_t realisation, void* half_out, void* stream);
 
 /* fused throughput path: generator inside the first inverse pass, then y and z (c2r) passes.
@@ -155,7 +155,7 @@ int fb_potential_k(fb_plan* plan, const void* dk, void* out, int layout, void* s
 /* out = exp(in)/mean(exp(in)) - 1 (box.py:457-460); *mean_out receives mean(exp(in)). Synchronises. */
 int fb_lognormal(fb_plan* plan, const void* real_in, void* real_out, double* mean_out, void* stream);
 /* redshift_space_density (box.py:405-437). noise: T[N][N][N] standard normals in LOS order
- * (parity) or NULL -> Threefry(seed) when sigma_nl > 0.                                           */
+ * (parity) or NULL -> Philox stream 1 of `seed` when sigma_nl > 0.                                          */
 int fb_redshift_space(fb_plan* plan, const void* delta, const void* vz, const void* noise, void* out,
                       double Hz, double sigma_nl, uint64_t seed, void* stream);
 /* sum(x) / sum(x^2) over a real field; sum |dk|^2 over the FULL grid from a half spectrum
@@ -287,6 +287,11 @@ int fb_set_tuning(fb_plan* plan, int stagger_plain, int stagger_gen, int stagger
  * their own streams, give each its share (e.g. 64 planes of a 512^3 box for two).  0 = whole box in one go.
  * streams = 2 sends alternate batches to a second stream of the plan; 0 = by grid size. */
 int fb_set_plane_batching(fb_plan* plan, int planes, int streams);
+/* Fused log-normal transforms (pre_exp of fb_fft_r2c / fb_power_spectrum_device / _pending) form exp(x - shift).  The
+ * estimate exp(d)/mean(exp(d)) - 1 does not depend on the shift (results[2 nbins] is the sum of the SHIFTED exponentials,
+ * which is what the caller normalises with); shift = sigma^2/2 of a Gaussian field keeps a single-precision plan's
+ * |delta_k|^2 and |delta_k|^4 sums finite when the field's variance is large (sigma ~ 8: exp(d) reaches 1e19). */
+int fb_set_exp_shift(fb_plan* plan, double shift);
 /* tuning aid: a single strided FFT pass over a half spectrum (axis 0 = x, 1 = y;
  * mode 0 plain in place, 1 fused generator, 2 fused binning without store) */
 int fb_debug_strided_pass(fb_plan* plan, void* half, int axis, int mode, void* stream);

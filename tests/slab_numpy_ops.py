@@ -38,6 +38,9 @@ class NumpySlabOps(object):
     def set_bins(self, bins, thr, amb):
         self.bins = np.asarray(bins)
 
+    def set_exp_shift(self, shift):
+        self.exp_shift = float(shift)
+
     def bin_counts(self):
         return hostgeom.bin_counts(self.N, self.g["L"][0], self.bins)
 
@@ -65,7 +68,7 @@ class NumpySlabOps(object):
     def forward_local(self, real, half_local, pre_exp, expsum):
         f = real.numpy()
         if pre_exp:
-            f = np.exp(f)
+            f = np.exp(f - getattr(self, "exp_shift", 0.0))
             expsum.numpy()[0] = f.sum()
         self._c(half_local)[:, :self.N, :self.nz] = np.fft.fft(np.fft.rfft(f, axis=2), axis=1)
 

@@ -190,3 +190,28 @@ def test_stale_runtime_error_of_another_library_is_not_reported():
     dx = box.realise_density()
     kc, pk, err = box.binned_power_spectrum(delta_x=dx, nbins=10)
     assert np.isfinite(pk[~np.isnan(pk)]).all()
+
+
+def test_monte_carlo_checkpoint_resume_on_the_device(tmp_path):
+    """fastbox_amd.montecarlo on a real box: a run killed after some batches resumes from its checkpoint and ends with
+    the sums of the uninterrupted run, bit for bit (realisations are addressed by index: counter-based generator)."""
+    from fastbox_amd import CosmoBox, default_cosmo, montecarlo
+    mk = lambda: CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=64, realise_now=False, rng="device", seed=7000)
+    full, kc, _ = montecarlo.run(mk(), 24, nbins=12, lognormal=True, batch=5)
+    ck = str(tmp_path / "mc.npz")
+
+    class Killed(Exception):
+        pass
+
+    def kill(done, total):
+        if done >= 10:
+            raise Killed()
+    with pytest.raises(Killed):
+        montecarlo.run(mk(), 24, nbins=12, lognormal=True, batch=5, checkpoint=ck, on_batch=kill)
+    acc, kc2, _ = montecarlo.run(mk(), 24, nbins=12, lognormal=True, batch=5, checkpoint=ck)
+    assert acc.n == 24 and np.array_equal(kc, kc2)
+    assert np.array_equal(acc.mean, full.mean) and np.array_equal(acc.m2, full.m2)
+    # two "ranks" on this GPU: the combined raw sums are those of one rank (to rounding of the merge)
+    parts = [montecarlo.run(mk(), 24, nbins=12, lognormal=True, batch=5, rank=r, world=2)[0] for r in range(2)]
+    tot = montecarlo.BandPowerAccumulator.from_raw_sums(*[sum(x) for x in zip(*[p.raw_sums() for p in parts])])
+    assert np.allclose(tot.mean, full.mean, rtol=1e-12) and np.allclose(tot.covariance(), full.covariance(), rtol=1e-9, atol=0)

@@ -1,0 +1,21 @@
+"""Build container: copy the summaries a GPU run of tools/collect_profiles.sh left under gpurun_out/prof_<tag>/ into
+profiles/<tag>_* and record in profiles/current.json which files bench.py's `from_profiles` object refers to and the
+commit the library was at when they were collected (the GPU box has no .git: stamp right after the run, before any
+further commit).    python tools/stamp_profiles.py r02"""
+import json, os, shutil, subprocess, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles")
+for name in sorted(os.listdir(src)):
+    if name.endswith((".csv", ".json", ".txt")):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
+head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "fastbox_amd", "bench.py"], capture_output=True, text=True).stdout.strip())
+json.dump({"head": head + ("+uncommitted changes" if dirty else ""), "tag": tag,
+           "pmc": "%s_pmc_fetch_write_summary.json" % tag,
+           "kernel_stats": "%s_kernel_stats_streams1.csv" % tag,
+           "note": "kernel_stats: rocprofv3 --kernel-trace --stats of `bench.py --streams 1` (kernels running alone, as in "
+                   "bench.py's own roofline pass); <tag>_kernel_stats.csv is the default two-stream command"},
+          open(os.path.join(dst, "current.json"), "w"), indent=1)
+print("stamped", head, "dirty" if dirty else "clean")

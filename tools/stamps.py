@@ -18,12 +18,22 @@ for _ in range(3):
     _lib.call("fb_debug_strided_pass", eng._plan, h.ptr, axis, mode, eng.stream)
 nt = 17 * N
 if mode == 2:
-    raw = np.zeros(2 * 20 * nt + nt * 8, dtype=np.int64)
+    raw = np.zeros(2 * 20 * nt + nt * 32, dtype=np.int64)
     _lib.call("fb_debug_read_stamps", eng._plan, raw.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), raw.size)
-    st = raw[2 * 20 * nt:].reshape(nt, 8)
+    full = raw[2 * 20 * nt:].reshape(nt, 32)
+    st = full[:, :8]
+    # per wave: end of its binning relative to the barrier that opened the binning phase (stamp 5)
+    wv = (full[:, 8:24] - full[:, 5:6]).astype(float)
+    print("binning phase per wave (ticks after the staging barrier): wave  median  mean  p90  max")
+    for w in range(16):
+        print("   wave %2d %8.0f %8.0f %8.0f %8.0f" % (w, np.median(wv[:, w]), wv[:, w].mean(), np.percentile(wv[:, w], 90), wv[:, w].max()))
+    slow = wv.max(axis=1)
+    print("slowest wave of a workgroup: median %.0f mean %.0f p90 %.0f; which wave is slowest (histogram):" % (np.median(slow), slow.mean(), np.percentile(slow, 90)),
+          np.bincount(wv.argmax(axis=1), minlength=16))
 else:
-    st = np.zeros((nt, 8), dtype=np.int64)
-    _lib.call("fb_debug_read_stamps", eng._plan, st.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), st.size)
+    full = np.zeros((nt, 32), dtype=np.int64)
+    _lib.call("fb_debug_read_stamps", eng._plan, full.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), full.size)
+    st = full[:, :8]
 t0 = st[:, 0].min()
 names = ["start->loads issued", "loads issued->landed", "landed->tables", "fft stages",
          "stores issued | p staged", "stores drained | binned", "(bin) partials written"]
