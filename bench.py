@@ -74,6 +74,8 @@ def parse(argv=None):
                     help="x-planes per cache-resident batch of the y/z passes (default: the library's size for one box per "
                          "GPU when --streams 1, N/8 when several boxes share the GPU)")
     ap.add_argument("--plane-streams", type=int, default=None, help="1 | 2 streams for alternate plane batches")
+    ap.add_argument("--stream-priorities", action="store_true",
+                    help="tuning aid: the first box's stream gets the device's highest priority, the others the lowest")
     ap.add_argument("--kernel-event-stride", type=int, default=7,
                     help="--streams 1: bracket every K-th launch of the roofline kernel with a HIP event pair inside "
                          "the timed region (an event pair costs ~3 us of stream time)")
@@ -187,12 +189,19 @@ def from_profiles(N, precision):
     return out
 
 
+def _prio(args, i):
+    """--stream-priorities: box 0 on the highest-priority stream, the others on the lowest (tuning aid)."""
+    if not getattr(args, "stream_priorities", False):
+        return None
+    return -1 if i == 0 else 1
+
+
 def _make_boxes(args, N, precision, n, rank, local_rank):
     from fastbox_amd import CosmoBox, default_cosmo
     from fastbox_amd.device import new_stream
     boxes = [CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, redshift=0., realise_now=False,
                       precision=precision, rng="device", seed=1000 * (rank + 1) + i, device=local_rank,
-                      stream=(new_stream(local_rank) if n > 1 else None)) for i in range(max(1, n))]
+                      stream=(new_stream(local_rank, _prio(args, i)) if n > 1 else None)) for i in range(max(1, n))]
     # several boxes share the GPU's 256 MiB Infinity Cache: each keeps a smaller plane batch resident
     # (512^3 fp32, two boxes: 64 planes = 2 x 70 MB of half spectrum + real planes; measured in profiles/r02_*)
     sz = 4 if precision == "f32" else 8

@@ -101,6 +101,7 @@ SIGNATURES = {
     "fb_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fb_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fb_stream_create": (c_int, [ctypes.POINTER(c_void_p)]),
+    "fb_stream_create_priority": (c_int, [ctypes.POINTER(c_void_p), c_int]),
     "fb_stream_destroy": (c_int, [c_void_p]),
     "fb_stream_sync": (c_int, [c_void_p]),
     "fb_device_count": (c_int, [ctypes.POINTER(c_int)]),

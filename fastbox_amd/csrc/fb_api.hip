@@ -696,6 +696,16 @@ int fb_stream_create(void** stream) {
     *stream = (void*)s;
     return FB_OK;
 }
+int fb_stream_create_priority(void** stream, int priority) {
+    FB_REQUIRE(stream, "null pointer");
+    int lo = 0, hi = 0;                                  // numerically lower = higher priority
+    FB_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    int pr = priority < 0 ? hi : (priority > 0 ? lo : (lo + hi) / 2);
+    hipStream_t s;
+    FB_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, pr));
+    *stream = (void*)s;
+    return FB_OK;
+}
 int fb_stream_destroy(void* stream) {
     if (stream) FB_HIP(hipStreamDestroy((hipStream_t)stream));
     return FB_OK;

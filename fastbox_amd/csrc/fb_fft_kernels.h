@@ -37,6 +37,9 @@ template <typename T> constexpr int tile_cols(int n) {
 #ifndef FB_GEN_STORE_AUX
 #define FB_GEN_STORE_AUX 0     // cache policy of the generator pass's stores (tuning: 2 = nt)
 #endif
+#ifndef FB_BIN_LOAD_AUX
+#define FB_BIN_LOAD_AUX 0      // cache policy of the binning pass's loads (tuning: 2 = nt)
+#endif
 #ifndef FB_OCC
 #define FB_OCC(x) 1      // let the allocator use what the prefetching loop needs (no spills)
 #endif
@@ -194,7 +197,19 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         }
     }
     do {    // PERSIST: tiles blockIdx.x, blockIdx.x + gridDim.x, ...; otherwise exactly one tile
-        const int bx = tile_id % a.ntx, by = tile_id / a.ntx;
+        int bx = tile_id % a.ntx;
+        const int by = tile_id / a.ntx;
+#ifndef FB_NO_XCD_PAIR
+        if constexpr (!PERSIST && TZ * sizeof(cx<T>) < 128) {
+            // Tiles narrower than a 128-byte line (N >= 1024: 64-byte row segments, 32 for fp64 at 2048): the LPT tiles
+            // that share every line of a row go to workgroups b, b + 8, b + 16, ... -- the same XCD under round-robin
+            // placement, started within the same dispatch wave -- so that a line is brought into ONE L2 once instead of
+            // into LPT different ones.  (Speed only: nothing depends on the placement.)
+            constexpr int LPT = 128 / (TZ * (int)sizeof(cx<T>)), G = 8 * LPT;
+            const int lg = bx % G;
+            if (bx - lg + G <= a.ntx) bx = (bx - lg) + LPT * (lg % 8) + lg / 8;
+        }
+#endif
         const int col = bx * TZ + c;
         const bool valid = col < a.ncols;
         const long long ubase = (long long)by * a.outer_stride + bx * TZ;
@@ -381,7 +396,10 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             const cx<T>* src = a.in + ubase + tbase;
             const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = buf_load(make_rsrc(src + eoff(e, a.blk_in)), voff, src);
+            for (int e = 0; e < E; ++e) {
+                if constexpr (smode_bins(MODE)) v[e] = buf_load<FB_BIN_LOAD_AUX>(make_rsrc(src + eoff(e, a.blk_in)), voff, src);
+                else v[e] = buf_load(make_rsrc(src + eoff(e, a.blk_in)), voff, src);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = vn[e];
@@ -713,8 +731,11 @@ template <typename T> struct ContigArgs {
     T exp_shift;            // pre_exp: transform exp(x - exp_shift) (fb_set_exp_shift: keeps a high-variance field's sums in range)
 };
 
+#ifndef FB_CONTIG_THREADS
+#define FB_CONTIG_THREADS 256      // threads per workgroup of the contiguous-axis passes (tuning: 128, 512)
+#endif
 template <int NF> constexpr int contig_lines() {   // lines per workgroup
-    return fb_max(1, 256 / (NF / elems_per_thread(NF)));
+    return fb_max(1, FB_CONTIG_THREADS / (NF / elems_per_thread(NF)));
 }
 
 // NF = complex transform length (N for c2c, N/2 for r2c/c2r)

@@ -170,14 +170,18 @@ class DeviceArray(NDArrayOperatorsMixin):
         return "DeviceArray(kind=%s, shape=%s, precision=%s)" % (self.kind, self.shape, self.engine.precision)
 
 
-def new_stream(device=None):
+def new_stream(device=None, priority=None):
     """A fresh non-blocking HIP stream (raw handle) for ``CosmoBox(..., stream=...)``: independent
     boxes on different streams overlap on the GPU (compute-bound passes of one with memory-bound
-    passes of the other).  ``device``: the GPU the stream is for (default: the current one)."""
+    passes of the other).  ``device``: the GPU the stream is for (default: the current one);
+    ``priority``: None (default), or < 0 / 0 / > 0 for the device's highest / middle / lowest stream priority."""
     if device is not None:
         _lib.call("fb_device_set", int(device))
     s = ctypes.c_void_p()
-    _lib.call("fb_stream_create", ctypes.byref(s))
+    if priority is None:
+        _lib.call("fb_stream_create", ctypes.byref(s))
+    else:
+        _lib.call("fb_stream_create_priority", ctypes.byref(s), int(priority))
     return s.value
 
 

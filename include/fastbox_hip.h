@@ -305,6 +305,7 @@ int fb_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* strea
 int fb_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int fb_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 int fb_stream_create(void** stream);     /* a non-blocking hipStream_t, for running independent boxes concurrently */
+int fb_stream_create_priority(void** stream, int priority);   /* priority < 0: the device's highest, 0: middle, > 0: lowest */
 int fb_stream_destroy(void* stream);
 int fb_stream_sync(void* stream);
 int fb_device_count(int* count);

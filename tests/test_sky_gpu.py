@@ -129,12 +129,16 @@ def test_pca_filter_matches_reference_vectors(golden_dir, name, precision, tol):
         # fit_powerlaw=True: the modes come from the covariance about the TRUE channel means (np.cov re-centres),
         # only the subtracted / restored spectrum is the power-law fit (filters.py:146-158)
         cleaned, U, amps = filters.pca_filter(cube, nm, fit_powerlaw=True, return_filter=True)
-        assert np.max(np.abs(np.asarray(cleaned) - g["cleaned_pl%d" % nm])) < tol * scale
+        # (fp32 storage of the cube moves the channel means by 1e-7, and the least-squares power-law fit of them -- which
+        # stays in the cleaned cube, since it is not the true mean spectrum -- answers with 5e-5)
+        assert np.max(np.abs(np.asarray(cleaned) - g["cleaned_pl%d" % nm])) < (tol if precision == "f64" else 2e-4) * scale
         Ur = g["U_pl%d" % nm].real
         assert np.max(np.abs(U @ U.T - Ur @ Ur.T)) < (1e-3 if precision == "f32" else 1e-9)
         sgn = np.sign(np.sum(U * Ur, axis=0))
         ref_amps = g["amps_pl%d" % nm].real
-        assert np.max(np.abs(amps * sgn[:, None] - ref_amps)) < (2e-3 if precision == "f32" else 1e-9) * np.max(np.abs(ref_amps))
+        # (the amplitudes carry the fitted spectrum, and scipy's curve_fit stops at a relative 1.5e-8: fed channel means
+        # that differ in the last bits it lands a few 1e-9 away; the cleaned cube above is insensitive to that)
+        assert np.max(np.abs(amps * sgn[:, None] - ref_amps)) < (1e-2 if precision == "f32" else 1e-7) * np.max(np.abs(ref_amps))
 
 
 def test_channel_covariance_on_the_matrix_cores_full_size():
