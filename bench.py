@@ -74,6 +74,9 @@ def parse(argv=None):
                     help="x-planes per cache-resident batch of the y/z passes (default: the library's size for one box per "
                          "GPU when --streams 1, N/8 when several boxes share the GPU)")
     ap.add_argument("--plane-streams", type=int, default=None, help="1 | 2 streams for alternate plane batches")
+    ap.add_argument("--gaussian-only", action="store_true",
+                    help="tuning aid: P(k) of the Gaussian field itself (no exp in the fused z pass); the line is then NOT "
+                         "BASELINE's configs[1]")
     ap.add_argument("--stream-priorities", action="store_true",
                     help="tuning aid: the first box's stream gets the device's highest priority, the others the lowest")
     ap.add_argument("--kernel-event-stride", type=int, default=7,
@@ -214,14 +217,14 @@ def _make_boxes(args, N, precision, n, rank, local_rank):
     return boxes
 
 
-def _step_fn(boxes, nbins):
+def _step_fn(boxes, nbins, lognormal=True):
     counter = [0]
 
     def step():
         box = boxes[counter[0] % len(boxes)]
         counter[0] += 1
         dx = box.realise_density()
-        return box.binned_power_spectrum(delta_x=box.lognormal(dx), nbins=nbins, wait=False)
+        return box.binned_power_spectrum(delta_x=box.lognormal(dx) if lognormal else dx, nbins=nbins, wait=False)
     return step
 
 
@@ -338,7 +341,7 @@ def main():
         return slab_main(args, rank, world, local_rank, torch, dist, np)
     nstreams = max(1, args.streams)
     boxes = _make_boxes(args, N, args.precision, nstreams, rank, local_rank)
-    step = _step_fn(boxes, args.nbins)
+    step = _step_fn(boxes, args.nbins, not args.gaussian_only)
     eng = boxes[0].engine
 
     def fence():
@@ -376,7 +379,7 @@ def main():
         # kernels of different boxes overlap in the timed region, so the roofline kernel is timed on its own here, on
         # ONE stream, directly before the warm-up steps (this pass also leaves the GPU at its sustained clocks)
         prof_steps = 40
-        one = _step_fn(boxes[:1], args.nbins)
+        one = _step_fn(boxes[:1], args.nbins, not args.gaussian_only)
         one().result()
         torch.cuda.synchronize()
         eng.profile_start(["fft_strided"], stride=1)
@@ -427,7 +430,8 @@ def main():
     achieved = alg_bytes / (ms / max(launches, 1) * 1e-3) / 1e9 if ms > 0 else None
     fp = from_profiles(N, args.precision)
     line = {
-        "metric": "%d^3 box realisations/sec (gen + log-normal + P(k))" % N,
+        "metric": "%d^3 box realisations/sec (gen + log-normal + P(k))" % N if not args.gaussian_only
+                  else "%d^3 box realisations/sec (gen + P(k), NO log-normal: tuning run)" % N,
         "value": world * args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",

@@ -48,6 +48,17 @@ template <int SIGN> __device__ __forceinline__ cx<float> pk_add_i(cx<float> a, c
     else                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(to_f2(a)), "v"(to_f2(b)));
     return to_cx(r);
 }
+// a + conj(b), a - conj(b)
+__device__ __forceinline__ cx<float> pk_add_conj(cx<float> a, cx<float> b) {
+    fb_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(to_f2(a)), "v"(to_f2(b)));
+    return to_cx(r);
+}
+__device__ __forceinline__ cx<float> pk_sub_conj(cx<float> a, cx<float> b) {
+    fb_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(to_f2(a)), "v"(to_f2(b)));
+    return to_cx(r);
+}
 // a * w (SIGN < 0) or a * conj(w) (SIGN > 0): tables hold forward twiddles
 template <int SIGN> __device__ __forceinline__ cx<float> pk_cmul(cx<float> a, cx<float> w) {
     fb_f2 r;

@@ -704,10 +704,18 @@ __global__ __launch_bounds__(256) void k_bin_packed_plane(const cx<T>* __restric
 // (relative error ~ |x| 2^-24 from the rounded product plus 1 ulp) instead of libm's expf.
 __device__ __forceinline__ double fb_exp(double x) { return exp(x); }
 __device__ __forceinline__ float fb_exp(float x) {
-#ifdef FB_FAST_EXP
-    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
-#else
+#ifdef FB_LIBM_EXP
     return expf(x);
+#else
+    // 2^(x log2 e) on the hardware exponential (1 ulp), with the product's rounding error and the constant's own
+    // truncation carried into a first-order correction: t + e = x log2(e) to ~2^-45 |x|, exp(x) = 2^t (1 + e ln 2).
+    // Same accuracy class as libm's expf (2 ulp over |x| < 80 given a correctly rounded 2^t: tests/test_host_math.py), 6
+    // instructions instead of 10 and no range-reduction branches; the fused z pass is issue-bound.
+    const float t = x * 1.44269502162933349609375f;                        // float(log2 e)
+    float e = __builtin_fmaf(x, 1.44269502162933349609375f, -t);           // exact rounding error of the product
+    e = __builtin_fmaf(x, 1.925963033500011e-8f, e);                       // log2 e - float(log2 e)
+    const float r = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(r, 0.693147182464599609375f * e, r);
 #endif
 }
 enum { ZMODE_C2C = 0, ZMODE_R2C = 1, ZMODE_C2R = 2, ZMODE_C2R2C = 3 };
@@ -764,26 +772,32 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
     for (int i = tid; i < M; i += NT) twl[i] = a.tw[i];
     const long long line = (long long)blockIdx.x * LPW + l;
     const bool valid = line < a.nlines;
+    const long long line_ld = valid ? line : 0;      // lines past the end (last workgroup only) load line 0 and store nothing:
+                                                     // no per-element branches in the load / exp loops
     LineLayout<T> lay{lines + l * LP};
 
     cx<T> v[E];
     if constexpr (MODE == ZMODE_C2R || MODE == ZMODE_C2R2C) {
         // Z[k] = (X[k] + conj X[n-k]) + i e^{+2 pi i k/N} (X[k] - conj X[n-k]); the
         // imaginary parts of X[0], X[n] are dropped (Hermitian projection).
-        const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in) + (line + (a.in_skip ? line / a.in_skip : 0)) * a.in_pitch;
+        const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in) + (line_ld + (a.in_skip ? line_ld / a.in_skip : 0)) * a.in_pitch;
         // (taking the untangle twiddles straight from the global table, so that the line's own loads are not held behind
         // this barrier, was measured slower: 0.3245 against 0.3062 ms per step for the fused z pass)
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int k = t + e * TPL;
-            cx<T> xk{0, 0}, xn{0, 0};
-            if (valid) { xk = in[k]; xn = in[a.packed ? ((NF - k) & (NF - 1)) : NF - k]; }
+            cx<T> xk = in[k], xn = in[a.packed ? ((NF - k) & (NF - 1)) : NF - k];
             if (k == 0) { if (a.packed) xn.x = xk.y; xk.y = 0; xn.y = 0; }
-            cx<T> s = xk + cconj(xn), d = xk - cconj(xn);
-            cx<T> w = cconj(twl[k]);
-            cx<T> wd = cmul(w, d);
-            v[e] = cx<T>{s.x - wd.y, s.y + wd.x};
+            if constexpr (sizeof(T) == 4) {          // packed forms: s + i conj(w) d in five instructions
+                const cx<T> s = pk_add_conj(xk, xn), d = pk_sub_conj(xk, xn);
+                v[e] = pk_add_i<+1>(s, pk_cmul<+1>(d, twl[k]));
+            } else {
+                cx<T> s = xk + cconj(xn), d = xk - cconj(xn);
+                cx<T> w = cconj(twl[k]);
+                cx<T> wd = cmul(w, d);
+                v[e] = cx<T>{s.x - wd.y, s.y + wd.x};
+            }
         }
         fft_stages<T, NF, E, +1, TWS, 1, LineLayout<T>, WAVE>(v, t, twl, lay);
         if (valid) {
@@ -795,14 +809,18 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
     if constexpr (MODE == ZMODE_R2C || MODE == ZMODE_C2R2C) {
         double esum = 0.0;
         if constexpr (MODE == ZMODE_R2C) {
-            const cx<T>* in = reinterpret_cast<const cx<T>*>(reinterpret_cast<const T*>(a.in) + line * a.in_pitch);
+            const cx<T>* in = reinterpret_cast<const cx<T>*>(reinterpret_cast<const T*>(a.in) + line_ld * a.in_pitch);
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = valid ? in[t + e * TPL] : cx<T>{0, 0};
+            for (int e = 0; e < E; ++e) v[e] = in[t + e * TPL];
         }
         if (a.pre_exp) {
+            T part = 0;                      // a thread's 2 E exponentials in T, then one double add
 #pragma unroll
-            for (int e = 0; e < E; ++e)
-                if (valid) { v[e].x = fb_exp(v[e].x - a.exp_shift); v[e].y = fb_exp(v[e].y - a.exp_shift); esum += (double)v[e].x + (double)v[e].y; }
+            for (int e = 0; e < E; ++e) {
+                v[e].x = fb_exp(v[e].x - a.exp_shift); v[e].y = fb_exp(v[e].y - a.exp_shift);
+                part += v[e].x + v[e].y;
+            }
+            esum = valid ? (double)part : 0.0;
         }
         if constexpr (MODE == ZMODE_R2C || !WAVE) __syncthreads();      // R2C: the twiddles; C2R2C: lines[] is this wave's own
         else exchange_sync<true>();
@@ -820,11 +838,19 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
             for (int e = 0; e < E; ++e) {
                 const int k = t + e * TPL;
                 cx<T> zk = v[e];
-                cx<T> zn = cconj(lay.at((NF - k) & (NF - 1)));
-                cx<T> s = zk + zn, d = zk - zn;
-                cx<T> wd = cmul(twl[k], d);
+                cx<T> res;
+                if constexpr (sizeof(T) == 4) {      // (s - i w d) / 2 with s = z_k + conj z_{n-k}, d = z_k - conj z_{n-k}
+                    const cx<T> zr = lay.at((NF - k) & (NF - 1));
+                    const cx<T> s = pk_add_conj(zk, zr), d = pk_sub_conj(zk, zr);
+                    res = cscale(pk_add_i<-1>(s, pk_cmul<-1>(d, twl[k])), (T)0.5 * sc);
+                } else {
+                    cx<T> zn = cconj(lay.at((NF - k) & (NF - 1)));
+                    cx<T> s = zk + zn, d = zk - zn;
+                    cx<T> wd = cmul(twl[k], d);
+                    res = cx<T>{(T)0.5 * (s.x + wd.y) * sc, (T)0.5 * (s.y - wd.x) * sc};
+                }
                 if (k == 0 && a.packed) out[0] = cx<T>{(zk.x + zk.y) * sc, (zk.x - zk.y) * sc};
-                else out[k] = cx<T>{(T)0.5 * (s.x + wd.y) * sc, (T)0.5 * (s.y - wd.x) * sc};
+                else out[k] = res;
                 if (k == 0 && !a.packed) out[NF] = cx<T>{(zk.x - zk.y) * sc, (T)0};
             }
         }

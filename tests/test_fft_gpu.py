@@ -82,3 +82,24 @@ def test_unsupported_size_fails_loudly():
     from fastbox_amd._lib import FastBoxError
     with pytest.raises(FastBoxError):
         _engine(24, "f32")
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-6), ("f64", 1e-12)])
+def test_fused_exponential_of_the_forward_transform(precision, tol):
+    """r2c with pre_exp (the log-normal fusion): the transform of exp(x) against numpy on the same stored x, and a
+    column whose every line is constant, where the k_z = 0 mode of a line is exactly N exp(x): the device exponential
+    (fb_exp: 2^(x log2 e) with a first-order correction of the product's rounding) over four decades of magnitude."""
+    from fastbox_amd.device import REAL
+    N = 32
+    eng = _engine(N, precision)
+    rng = np.random.RandomState(3)
+    x = 1.5 * rng.normal(size=(N, N, N))
+    x[:, 0, :] = np.linspace(-9., 9., N)[:, None]                  # constant along z: e^-9 ... e^9
+    d = eng.upload(x, REAL)
+    xin = d.host().copy()
+    got = eng.fft_r2c(d, pre_exp=True).host()
+    want = np.fft.fftn(np.exp(xin))
+    assert _err(got, want) < tol
+    # the constant lines: sum over y of the first transform's k_z = 0 mode is the only place they enter with weight
+    # N exp(x); compare the (k_x, k_y = all, k_z = 0) plane, which is linear in exp(x[:, 0, 0]) up to the other rows
+    assert np.max(np.abs(got[:, :, 0] - want[:, :, 0])) < tol * np.max(np.abs(want[:, :, 0]))
