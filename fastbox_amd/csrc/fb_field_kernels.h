@@ -702,6 +702,14 @@ __device__ __forceinline__ double fmod_pos(double a, double b) {
 
 constexpr int FB_RSD_WAVES = 4;
 
+// A line of sight is one wave's: its key / value arrays are touched by no other wave, and a wave's LDS instructions
+// (atomics included) execute in issue order, so between the phases the compiler only has to be kept from reordering
+// -- no workgroup barrier, and the block's four lines of sight do not run in lockstep.
+__device__ __forceinline__ void rsd_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <typename T, int E>
 __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise, T* __restrict__ out,
@@ -794,12 +802,12 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         cell[e] = c;
         atomicMax(&kex[c], kb[e]);
     }
-    __syncthreads();
+    rsd_wave_sync();
 #pragma unroll
     for (int e = 0; e < E; ++e)
         if (kex[cell[e]] == kb[e]) vex[cell[e]] = val[e];
     const double fill = 0.5 * ((double)d[0] + (double)d[N - 1]);
-    __syncthreads();
+    rsd_wave_sync();
     // nearest non-empty cell strictly below / at-or-above each of this lane's cells
     u64 cmx[E];
     int last = -1, first = N;
@@ -840,18 +848,18 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
             if (cmx[e] != 0ull) rb = lane * E + e;
         }
     }
-    __syncthreads();
+    rsd_wave_sync();
     // second use of the arrays: per-cell minima
 #pragma unroll
     for (int e = 0; e < E; ++e) kex[lane + 64 * e] = ~0ull;
-    __syncthreads();
+    rsd_wave_sync();
 #pragma unroll
     for (int e = 0; e < E; ++e) atomicMin(&kex[cell[e]], kb[e]);
-    __syncthreads();
+    rsd_wave_sync();
 #pragma unroll
     for (int e = 0; e < E; ++e)
         if (kex[cell[e]] == kb[e]) vex[cell[e]] = val[e];
-    __syncthreads();
+    rsd_wave_sync();
     T y_out[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
