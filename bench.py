@@ -217,14 +217,15 @@ def _make_boxes(args, N, precision, n, rank, local_rank):
     return boxes
 
 
-def _step_fn(boxes, nbins, lognormal=True):
+def _step_fn(boxes, nbins, lognormal=True, keep_field=True):
     counter = [0]
 
     def step():
         box = boxes[counter[0] % len(boxes)]
         counter[0] += 1
         dx = box.realise_density()
-        return box.binned_power_spectrum(delta_x=box.lognormal(dx) if lognormal else dx, nbins=nbins, wait=False)
+        return box.binned_power_spectrum(delta_x=box.lognormal(dx) if lognormal else dx, nbins=nbins, wait=False,
+                                         keep_field=keep_field)
     return step
 
 
@@ -245,11 +246,12 @@ def _timed_steps(step, steps, warmup, sync):
     return time.perf_counter() - t0
 
 
-def quick_rate(args, N, precision, steps, warmup, rank, local_rank, torch):
+def quick_rate(args, N, precision, steps, warmup, rank, local_rank, torch, keep_field=True):
     """boxes/s of the benchmarked step at another size / precision (short run, same streams setting)."""
     boxes = _make_boxes(args, N, precision, args.streams, rank, local_rank)
     try:
-        dt = _timed_steps(_step_fn(boxes, args.nbins), steps, max(warmup, len(boxes)), torch.cuda.synchronize)
+        dt = _timed_steps(_step_fn(boxes, args.nbins, keep_field=keep_field), steps, max(warmup, len(boxes)),
+                          torch.cuda.synchronize)
     finally:
         for b in boxes:
             b.engine.close()
@@ -363,6 +365,14 @@ def main():
         other = "f64" if args.precision == "f32" else "f32"
         guarded(other, lambda: quick_rate(args, N, other, 10, 2, rank, local_rank, torch))
         guarded("config3", lambda: config3_leg(N, local_rank, torch))
+
+        def spectra_only():
+            r = quick_rate(args, N, args.precision, 100, 10, rank, local_rank, torch, keep_field=False)
+            r["note"] = "NOT the headline: the same step with binned_power_spectrum(..., keep_field=False) -- delta_x is not " \
+                        "written by the fused z pass (4.0 instead of 4.5 sweeps moved; a Monte-Carlo covariance run, " \
+                        "fastbox_amd/montecarlo.py, needs the spectra only and can redraw any realisation by index)"
+            return r
+        guarded("spectra_only_variant", spectra_only)
         if world == 1:
             def sizes():
                 out = {}

@@ -15,6 +15,8 @@ counter-based Philox4x32-10 RNG for throughput, reproducible on the host with
 No CPU fallback exists: without the HIP library or a GPU every compute method
 raises.
 """
+import weakref
+
 import numpy as np
 
 from . import hostgeom
@@ -166,10 +168,11 @@ class PendingDensity(DeviceArray):
     runs that pass; ``binned_power_spectrum(delta_x=...)`` of it (or of its log-normal) instead
     fuses the pass with the power spectrum's first one, and fills in delta_x on the way."""
 
-    def __init__(self, engine, pending_half, generator=None):
+    def __init__(self, engine, pending_half, generator=None, regenerate=None):
         DeviceArray.__init__(self, engine, REAL, None)
         self._pending = pending_half
         self.generator = generator      # (amp_key, seed, realisation): enough to regenerate delta_k
+        self._regenerate = regenerate   # () -> real DeviceArray of the same realisation (counter-based generator)
 
     @property
     def materialised(self):
@@ -181,7 +184,12 @@ class PendingDensity(DeviceArray):
     @property
     def ptr(self):
         if self._buf is None:
-            self._adopt(self.engine.realise_finish(self._pending))
+            if self._pending is not None:
+                self._adopt(self.engine.realise_finish(self._pending))
+            else:
+                # the pending spectrum went into a power spectrum that was asked not to keep the field
+                # (binned_power_spectrum(..., keep_field=False)): draw the same realisation again
+                self._adopt(self._regenerate())
         return self._buf.ptr
 
 
@@ -370,8 +378,18 @@ class CosmoBox(object):
         else:
             # generator fused into the first inverse FFT pass (no coloured spectrum round trip); the
             # last pass is deferred so that a following P(k) can fuse it with its own first pass
-            delta_x = PendingDensity(eng, eng.realise_begin(self.seed, self._realisation),
-                                     generator=(self._amp_key, self.seed, self._realisation))
+            amp_key, seed, real = self._amp_key, self.seed, self._realisation
+            wbox = weakref.ref(self)      # (no reference cycle box -> delta_x -> closure -> box: a dropped field must
+                                          # give its buffer back at once, not at the next garbage collection)
+
+            def again():
+                box = wbox()
+                if box is None:
+                    raise RuntimeError("the CosmoBox that drew this field is gone; it cannot be drawn again")
+                box._set_amplitude(*amp_key)
+                return box.engine.realise_fused(seed, real)
+            delta_x = PendingDensity(eng, eng.realise_begin(seed, real), generator=(amp_key, seed, real),
+                                     regenerate=again)
             self.last_realisation = self._realisation
             self._realisation += 1
         if inplace:
@@ -555,12 +573,15 @@ class CosmoBox(object):
         self._bin_cache[key] = (bins, kc, thr, amb)
         return self._bin_cache[key]
 
-    def binned_power_spectrum(self, delta_x=None, delta_k=None, nbins=20, kbins=None, wait=True):
+    def binned_power_spectrum(self, delta_x=None, delta_k=None, nbins=20, kbins=None, wait=True, keep_field=True):
         """Shell-averaged power spectrum of the realisation (box.py:696-768): bin centres,
         mean of |delta_k|^2/boxfactor and std/sqrt(n) per bin; bin 0 is dropped and empty
         bins are NaN, as in the reference.  ``wait=False`` (additive) returns a
         ``PendingSpectrum`` at once; its ``result()`` gives the same triple later, so that
-        many realisations can be queued without a host round trip each."""
+        many realisations can be queued without a host round trip each.
+        ``keep_field=False`` (additive; device-generator realisations whose last pass is still pending): the fused
+        z pass does not write delta_x -- a Monte-Carlo loop that only wants spectra saves an eighth of the step's
+        traffic; reading the field afterwards draws the same realisation again (same seed, same index)."""
         if delta_x is not None and delta_k is not None:
             raise ValueError("delta_x and delta_k specified; can only specify one")
         bins, kc, thr, amb = self._bin_setup(nbins, kbins)
@@ -597,9 +618,12 @@ class CosmoBox(object):
             # exp(d)/<exp(d)> - 1 is the same, and a single-precision plan's sums stay finite for sigma ~ 8
             # (a non-linear P(k) sampled at 2 Mpc: exp(d) reaches 1e19, |delta_k|^4 would overflow)
             shift = 0.5 * getattr(self, "_sigma2", 0.0) if (ln and src is getattr(self, "delta_x", None)) else 0.0
-            if isinstance(src, PendingDensity) and not src.materialised:
-                res, real = eng.power_pending(src._pending, pre_exp=ln, exp_shift=shift)     # z passes fused
-                src._adopt(real)
+            if isinstance(src, PendingDensity) and not src.materialised and src._pending is not None:
+                res, real = eng.power_pending(src._pending, pre_exp=ln, exp_shift=shift, keep_field=keep_field)     # z passes fused
+                if real is not None:
+                    src._adopt(real)
+                else:
+                    src._pending = None        # consumed; reading the field later regenerates it
             else:
                 res, _ = eng.power_fused(src, pre_exp=ln, exp_shift=shift)
             pending = PendingSpectrum(eng, res, bins.size, kc, self.boxfactor, self.N ** 3 if ln else None, None)

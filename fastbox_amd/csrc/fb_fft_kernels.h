@@ -800,10 +800,12 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
             }
         }
         fft_stages<T, NF, E, +1, TWS, 1, LineLayout<T>, WAVE>(v, t, twl, lay);
-        if (valid) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = cscale(v[e], a.scale);
+        if (valid && a.out) {                          // C2R2C with no real output: the field is only passed on
             cx<T>* out = reinterpret_cast<cx<T>*>(reinterpret_cast<T*>(a.out) + line * a.out_pitch);
 #pragma unroll
-            for (int e = 0; e < E; ++e) { v[e] = cscale(v[e], a.scale); out[t + e * TPL] = v[e]; }
+            for (int e = 0; e < E; ++e) out[t + e * TPL] = v[e];
         }
     }
     if constexpr (MODE == ZMODE_R2C || MODE == ZMODE_C2R2C) {

@@ -497,14 +497,14 @@ class Engine(object):
             _lib.call("fb_set_exp_shift", self._plan, float(shift))
             self._exp_shift = float(shift)
 
-    def power_pending(self, pend, pre_exp=False, exp_shift=0.0):
-        """Fused z pass (writes delta_x) + P(k) of (exp of) it.  Returns (results buffer, delta_x).
-        exp_shift: the exponentials are formed as exp(x - exp_shift) (fb_set_exp_shift)."""
+    def power_pending(self, pend, pre_exp=False, exp_shift=0.0, keep_field=True):
+        """Fused z pass (writes delta_x unless keep_field is False) + P(k) of (exp of) it.  Returns (results buffer,
+        delta_x or None).  exp_shift: the exponentials are formed as exp(x - exp_shift) (fb_set_exp_shift)."""
         self._set_exp_shift(exp_shift if pre_exp else getattr(self, "_exp_shift", 0.0))
         res = self._result_slot()
-        out = self.empty(REAL)
-        _lib.call("fb_power_spectrum_pending", self._plan, pend.ptr, out.ptr, 1 if pre_exp else 0, res.ptr,
-                  self.stream)
+        out = self.empty(REAL) if keep_field else None
+        _lib.call("fb_power_spectrum_pending", self._plan, pend.ptr, out.ptr if keep_field else None,
+                  1 if pre_exp else 0, res.ptr, self.stream)
         return res, out
 
     def power_fused(self, real, pre_exp=False, keep_spectrum=False, exp_shift=0.0):

@@ -67,7 +67,7 @@ def _load(path):
 
 
 def run(box, realisations, nbins=20, lognormal=False, batch=50, rank=0, world=1, checkpoint=None,
-        checkpoint_every=1, on_batch=None):
+        checkpoint_every=1, on_batch=None, keep_fields=False):
     """P(k) of realisations r = rank, rank + world, ... < `realisations` of ``box`` (a CosmoBox with rng='device').
 
     ``checkpoint``: file of this rank's state, written after every ``checkpoint_every`` batches and read at the start
@@ -84,6 +84,8 @@ def run(box, realisations, nbins=20, lognormal=False, batch=50, rank=0, world=1,
             raise ValueError("checkpoint %s belongs to another run: %s" % (checkpoint, meta))
         acc, kc, done = acc0, kc0, int(meta["done"])
     mine = [r for r in range(realisations) if r % world == rank]
+    # the covariance needs the spectra only: the fused z pass does not write delta_x (it can be drawn again by index)
+    spectra_only = {} if keep_fields else {"keep_field": False}
     t0 = time.perf_counter()
     nb = 0
     for start in range(done, len(mine), batch):
@@ -92,7 +94,8 @@ def run(box, realisations, nbins=20, lognormal=False, batch=50, rank=0, world=1,
         for r in chunk:
             box._realisation = r                     # the generator's counter: realisation r, whatever ran before
             dx = box.realise_density()
-            pend.append(box.binned_power_spectrum(delta_x=box.lognormal(dx) if lognormal else dx, nbins=nbins, wait=False))
+            pend.append(box.binned_power_spectrum(delta_x=box.lognormal(dx) if lognormal else dx, nbins=nbins, wait=False,
+                                                  **spectra_only))
         for p in pend:
             kc, pk, _ = p.result()
             acc.add(pk)

@@ -132,7 +132,9 @@ int fb_power_spectrum_filtered(fb_plan* plan, const void* real_in, void* filtere
  * work_half is scratch and holds fftn(real_in) afterwards only if keep_spectrum.              */
 int fb_power_spectrum_device(fb_plan* plan, const void* real_in, void* work_half, int pre_exp,
                              int keep_spectrum, double* results_dev, void* stream);
-/* same results for a field still pending from fb_realise_density_begin (see there); consumes pending_half */
+/* same results for a field still pending from fb_realise_density_begin (see there); consumes pending_half.
+ * real_out = NULL: delta_x itself is not written (a Monte-Carlo loop that only wants the spectrum; the realisation can
+ * be regenerated from (seed, realisation) at any time) -- a quarter of the fused z pass's traffic less.            */
 int fb_power_spectrum_pending(fb_plan* plan, void* pending_half, void* real_out, int pre_exp, double* results_dev,
                               void* stream);
 /* number of full-grid modes per bin for the current bin set (host array, nbins doubles) */

@@ -215,3 +215,22 @@ def test_monte_carlo_checkpoint_resume_on_the_device(tmp_path):
     parts = [montecarlo.run(mk(), 24, nbins=12, lognormal=True, batch=5, rank=r, world=2)[0] for r in range(2)]
     tot = montecarlo.BandPowerAccumulator.from_raw_sums(*[sum(x) for x in zip(*[p.raw_sums() for p in parts])])
     assert np.allclose(tot.mean, full.mean, rtol=1e-12) and np.allclose(tot.covariance(), full.covariance(), rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("N", [64, 512])
+def test_spectrum_without_keeping_the_field(N):
+    """binned_power_spectrum(..., keep_field=False) on a pending device-generator realisation: the fused z pass does not
+    write delta_x; the spectrum is the same bit for bit, and reading the field afterwards draws the same realisation
+    again (counter-based generator)."""
+    from fastbox_amd import CosmoBox, default_cosmo
+    mk = lambda: CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False, precision="f32", rng="device", seed=21)
+    a, b = mk(), mk()
+    for ln in (False, True):
+        da, db = a.realise_density(), b.realise_density()
+        pa = a.binned_power_spectrum(delta_x=a.lognormal(da) if ln else da, nbins=20, wait=False)
+        pb = b.binned_power_spectrum(delta_x=b.lognormal(db) if ln else db, nbins=20, wait=False, keep_field=False)
+        assert da.materialised and not db.materialised
+        for x, y in zip(pa.result(), pb.result()):
+            assert np.array_equal(x, y, equal_nan=True)
+        fa, fb = np.asarray(da), np.asarray(db)                  # the second one is regenerated here
+        assert db.materialised and np.array_equal(fa, fb)

@@ -33,7 +33,7 @@ class _FakeBox(object):
     def lognormal(self, dx):
         return ("ln", dx)
 
-    def binned_power_spectrum(self, delta_x, nbins, wait):
+    def binned_power_spectrum(self, delta_x, nbins, wait, keep_field=True):
         r = delta_x[1] if isinstance(delta_x, tuple) else delta_x
         g = np.random.RandomState(1000 + r)
         pk = 5. + g.normal(size=nbins - 1)
