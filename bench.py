@@ -382,6 +382,9 @@ def main():
                         out[str(n2)] = quick_rate(args, n2, args.precision, st, 2, rank, local_rank, torch)
                 return out
             guarded("sizes", sizes)
+    if world > 1:
+        dist.barrier()                    # the other ranks wait HERE for rank 0's legs, so that every rank spins its GPU up
+                                          # directly before the timed region (an idle GPU lowers its clocks again)
     in_region = nstreams == 1             # event brackets inside the timed region only when kernels run alone
     ev_stride = 1 if args.all_kernel_events else max(1, args.kernel_event_stride)
     prof_steps = args.steps
