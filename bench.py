@@ -488,15 +488,21 @@ def main():
         # one box over all ranks, as child jobs (the other ranks of this job have left their GPUs by now)
         out = {}
         torch.cuda.empty_cache()
+        failed = False
         for n2 in [int(x) for x in args.slab_sizes.split(",") if x]:
             st = 10 if n2 <= 1024 else 5
+            if failed:                                  # do not spend another time-out on a transport that does not work
+                out[str(n2)] = {"error": "skipped: the previous slab job failed"}
+                continue
             try:
                 rc, txt = spawn_ranks(world, ["--mode", "slab", "--nsamp", str(n2), "--steps", str(st), "--warmup", "2",
-                                              "--gpus", str(world), "--precision", args.precision], timeout=420)
+                                              "--gpus", str(world), "--precision", args.precision], timeout=240)
                 j = _last_json(txt)
                 out[str(n2)] = j if (rc == 0 and j) else {"error": "slab job rc=%s" % rc}
+                failed = not (rc == 0 and j)
             except Exception as e:
                 out[str(n2)] = {"error": "%s: %s" % (type(e).__name__, e)}
+                failed = True
         line["strong_scaling"] = out
     if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
         line["cpu_baseline"] = cpu_baseline(N, args.cpu_nsamp or (N if N <= 512 else 256), args.nbins)
