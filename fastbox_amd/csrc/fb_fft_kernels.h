@@ -141,6 +141,10 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     const bool stamp_ok = (smode_bins(MODE)) ? (op.partial != nullptr) : (op.bins != nullptr);
 #define FB_STAMP(k) do { if (tid == 0 && stamp_ok) stamp[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     FB_STAMP(0);
+    if (tid == 0 && stamp_ok) {                // where the workgroup ran: HW_ID (CU / SE) and XCC_ID, raw
+        stamp[24] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        stamp[25] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
 #else
 #define FB_STAMP(k) do {} while (0)
 #endif
@@ -199,6 +203,13 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     do {    // PERSIST: tiles blockIdx.x, blockIdx.x + gridDim.x, ...; otherwise exactly one tile
         int bx = tile_id % a.ntx;
         const int by = tile_id / a.ntx;
+#ifndef FB_NO_TILE_ROTATE
+        // Workgroup b runs on XCD b % 8 and ntx is a multiple of 8 at every power-of-two size, so without this every
+        // row's tile 0 -- the self-mirrored planes of the generator, twice the draws of any other tile -- would land on
+        // XCD 0, which then finishes 60 % after the other seven (tools/phase_timeline.py).  Rotating the tile index by
+        // the row number deals the heavy tiles round all eight XCDs.  (Speed only: nothing depends on the placement.)
+        if constexpr (!PERSIST) bx = (bx + by) % a.ntx;
+#endif
 #ifndef FB_NO_XCD_PAIR
         if constexpr (!PERSIST && TZ * sizeof(cx<T>) < 128) {
             // Tiles narrower than a 128-byte line (N >= 1024: 64-byte row segments, 32 for fp64 at 2048): the LPT tiles
