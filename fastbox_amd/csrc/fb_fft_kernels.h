@@ -26,12 +26,21 @@ constexpr int strided_elems(int n) { return n >= FB_E16_FROM ? 16 : fb_min(8, n)
 // columns per tile of the strided pass: one 128-byte row segment, shrunk so the
 // tile stays within 64 KiB of LDS (two workgroups per CU), and widened for tiny grids so
 // that a workgroup is at least one full wave.
+#ifndef FB_TILE_LINE
+#define FB_TILE_LINE 128      // bytes of a tile's row segment (tuning: 64 = half-line tiles, four workgroups per CU at 512^3)
+#endif
 template <typename T> constexpr int tile_cols(int n) {
-    return fb_max(fb_max(2, fb_min(128 / (2 * (int)sizeof(T)),
+    return fb_max(fb_max(2, fb_min(FB_TILE_LINE / (2 * (int)sizeof(T)),
                                    // 16 points per thread: 128 KB tile (fp32), 64 KB for fp64 so that the tile, the
                                    // fp64 twiddles (32 KB at 2048) and the binning rows stay within the 160 KB of a CU
                                    (n >= FB_E16_FROM ? (sizeof(T) == 8 ? 65536 : 131072) : 65536) / (n * 2 * (int)sizeof(T)))),
                   64 / (n / strided_elems(n)));
+}
+
+// workgroups of the strided pass that share a CU: bounded by the tile's LDS (160 KB per CU) and by 2048 threads
+template <typename T> constexpr int strided_wg_per_cu(int n) {
+    const int tile = n * tile_cols<T>(n) * 2 * (int)sizeof(T), nt = tile_cols<T>(n) * (n / strided_elems(n));
+    return fb_max(1, fb_min(2048 / nt, tile > 81920 ? 1 : tile > 36864 ? 2 : 4));
 }
 
 #ifndef FB_GEN_STORE_AUX
@@ -99,7 +108,7 @@ template <typename T> struct StridedOp {
 // PERSIST = false: one tile per workgroup, two workgroups per CU (<= 64 VGPRs at 1024 threads).
 template <typename T, int N, int MODE, int PERSIST>   // 0: one tile per workgroup; 1: loop + register prefetch; 2: loop only
 __global__ __launch_bounds__(tile_cols<T>(N) * (N / strided_elems(N)),
-                             PERSIST == 1 ? 1 : fb_min(8, fb_max(1, (N * tile_cols<T>(N) * 2 * (int)sizeof(T) > 81920 ? 1 : 2)
+                             PERSIST == 1 ? 1 : fb_min(8, fb_max(1, strided_wg_per_cu<T>(N)
                                                                      * tile_cols<T>(N) * (N / strided_elems(N)) / 256)))
 void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     constexpr int E = strided_elems(N);
@@ -184,10 +193,34 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             if (r * 64 < op.nbins) b += __builtin_popcountll(__ballot(thrv[r] <= n2));
         return b;
     };
+    // tile number -> (tile column bx, outer index by).  Speed only: nothing depends on the placement.
+    auto place = [&](int id, int& bx, int& by) {
+        bx = id % a.ntx;
+        by = id / a.ntx;
+#ifndef FB_NO_TILE_ROTATE
+        // Workgroup b runs on XCD b % 8 and ntx is a multiple of 8 at every power-of-two size, so without this every
+        // row's tile 0 -- the self-mirrored planes of the generator, twice the draws of any other tile -- would land on
+        // XCD 0, which then finishes 60 % after the other seven (tools/phase_timeline.py).  Rotating the tile index by
+        // the row number deals the heavy tiles round all eight XCDs.
+        bx = (bx + by) % a.ntx;
+#endif
+#ifndef FB_NO_XCD_PAIR
+        if constexpr (TZ * sizeof(cx<T>) < 128) {
+            // Tiles narrower than a 128-byte line (N >= 1024: 64-byte row segments, 32 for fp64 at 2048): the LPT tiles
+            // that share every line of a row go to workgroups b, b + 8, b + 16, ... -- the same XCD under round-robin
+            // placement, started within the same dispatch wave -- so that a line is brought into ONE L2 once instead of
+            // into LPT different ones.
+            constexpr int LPT = 128 / (TZ * (int)sizeof(cx<T>)), G = 8 * LPT;
+            const int lg = bx % G;
+            if (bx - lg + G <= a.ntx) bx = (bx - lg) + LPT * (lg % 8) + lg / 8;
+        }
+#endif
+    };
     int tile_id = blockIdx.x;
     if constexpr (MODE != SMODE_GEN && PERSIST == 1) {          // the launcher guarantees gridDim.x <= ntiles
-        const int bx0 = tile_id % a.ntx;
-        const cx<T>* src = a.in + ((long long)(tile_id / a.ntx) * a.outer_stride + bx0 * TZ + tbase);
+        int bx0, by0;
+        place(tile_id, bx0, by0);
+        const cx<T>* src = a.in + ((long long)by0 * a.outer_stride + bx0 * TZ + tbase);
         const unsigned voff = bx0 * TZ + c < a.ncols ? loff : FB_BUF_OOB;
 #pragma unroll
         for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + eoff(e, a.blk_in)), voff, src);
@@ -201,26 +234,8 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         }
     }
     do {    // PERSIST: tiles blockIdx.x, blockIdx.x + gridDim.x, ...; otherwise exactly one tile
-        int bx = tile_id % a.ntx;
-        const int by = tile_id / a.ntx;
-#ifndef FB_NO_TILE_ROTATE
-        // Workgroup b runs on XCD b % 8 and ntx is a multiple of 8 at every power-of-two size, so without this every
-        // row's tile 0 -- the self-mirrored planes of the generator, twice the draws of any other tile -- would land on
-        // XCD 0, which then finishes 60 % after the other seven (tools/phase_timeline.py).  Rotating the tile index by
-        // the row number deals the heavy tiles round all eight XCDs.  (Speed only: nothing depends on the placement.)
-        if constexpr (!PERSIST) bx = (bx + by) % a.ntx;
-#endif
-#ifndef FB_NO_XCD_PAIR
-        if constexpr (!PERSIST && TZ * sizeof(cx<T>) < 128) {
-            // Tiles narrower than a 128-byte line (N >= 1024: 64-byte row segments, 32 for fp64 at 2048): the LPT tiles
-            // that share every line of a row go to workgroups b, b + 8, b + 16, ... -- the same XCD under round-robin
-            // placement, started within the same dispatch wave -- so that a line is brought into ONE L2 once instead of
-            // into LPT different ones.  (Speed only: nothing depends on the placement.)
-            constexpr int LPT = 128 / (TZ * (int)sizeof(cx<T>)), G = 8 * LPT;
-            const int lg = bx % G;
-            if (bx - lg + G <= a.ntx) bx = (bx - lg) + LPT * (lg % 8) + lg / 8;
-        }
-#endif
+        int bx, by;
+        place(tile_id, bx, by);
         const int col = bx * TZ + c;
         const bool valid = col < a.ncols;
         const long long ubase = (long long)by * a.outer_stride + bx * TZ;
@@ -419,8 +434,9 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             // a branch here makes the compiler's in-order vmcnt bookkeeping pessimistic and it
             // then waits for these loads before the current tile's first butterfly.
             const int nxt = tile_id + gridDim.x;
-            const int nbx = nxt % a.ntx;
-            const cx<T>* src = a.in + ((long long)(nxt / a.ntx) * a.outer_stride + nbx * TZ + tbase);
+            int nbx, nby;
+            place(nxt, nbx, nby);
+            const cx<T>* src = a.in + ((long long)nby * a.outer_stride + nbx * TZ + tbase);
             const unsigned voff = (nxt < a.ntiles && nbx * TZ + c < a.ncols) ? loff : FB_BUF_OOB;
 #pragma unroll
             for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + eoff(e, a.blk_in)), voff, src);

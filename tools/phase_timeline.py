@@ -21,50 +21,51 @@ dx = box.realise_density()
 box.binned_power_spectrum(delta_x=dx)
 for _ in range(3):
     _lib.call("fb_debug_strided_pass", eng._plan, h.ptr, axis, mode, eng.stream)
-nt = 16 * N
-full = np.zeros((nt, 32), dtype=np.int64)
-_lib.call("fb_debug_read_stamps", eng._plan, full.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), full.size)
+if mode == 2:                                  # the binning pass keeps its stamps behind the partial sums; unpacked layout
+    nt = 17 * N
+    raw = np.zeros(2 * 20 * nt + nt * 32, dtype=np.int64)
+    _lib.call("fb_debug_read_stamps", eng._plan, raw.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), raw.size)
+    full = raw[2 * 20 * nt:].reshape(nt, 32).copy()
+    full[:, 6] = full[:, 7]                    # "end" = partial sums written
+else:
+    nt = 16 * N
+    full = np.zeros((nt, 32), dtype=np.int64)
+    _lib.call("fb_debug_read_stamps", eng._plan, full.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), full.size)
 if os.environ.get("FB_STAMPS_DUMP"):
     np.save(os.environ["FB_STAMPS_DUMP"], full)
 st = full[:, :8].astype(np.int64)
-hw = full[:, 24]
-print("XCC_ID register values seen:", np.unique(full[:, 25] & 0xf))
-xcc = np.arange(nt) % 8                        # workgroups go to the XCDs round robin
-for x in np.unique(xcc):                       # every XCD counts from its own origin: align on each XCD's first start
-    st[xcc == x] -= st[xcc == x][:, 0].min()
-print("start stamps after alignment: percentiles 0/1/50/99/100:", np.percentile(st[:, 0], [0, 1, 50, 99, 100]))
-print("end   stamps after alignment: percentiles 0/1/50/99/100:", np.percentile(st[:, 6], [0, 1, 50, 99, 100]))
-for x in range(8):
-    m = xcc == x
-    print("  XCD %d: register says %s, starts %d..%d, ends %d..%d" % (x, np.unique(full[m, 25] & 0xf), st[m, 0].min(), st[m, 0].max(), st[m, 6].min(), st[m, 6].max()))
-span = int(np.percentile(st[:, 6], 99.5))
-keep = (st[:, 6] <= span) & (st[:, 0] >= 0)
-print("kept %d of %d workgroups" % (keep.sum(), len(keep)))
-st, hw, xcc = st[keep], hw[keep], xcc[keep]
-assert 0 < span < 10 ** 7, "time stamps out of range: %d" % span
-cu = ((xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)).astype(np.int64)
-print("workgroups %d, span %d ticks (%.1f us), distinct CUs %d" % (len(st), span, span / 100.0, len(np.unique(cu))))
-for nm, a, b in (("start->fft input ready", 0, 3), ("fft", 3, 4), ("epilogue, stores issued", 4, 5), ("stores drained", 5, 6), ("lifetime", 0, 6)):
+hw, xcc = full[:, 24], full[:, 25] & 0xf
+cu = ((xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)).astype(np.int64)
+ntx = 17 if mode == 2 else 16
+bx = np.arange(nt) % ntx
+life = (st[:, 6] - st[:, 0]).astype(float)
+print("workgroups %d on %d CUs; s_memtime ticks are shader clocks (about 2.4 GHz), each CU counts from its own origin" % (nt, len(np.unique(cu))))
+for nm, a, b in (("start->fft input ready", 0, 3), ("fft", 3, 4), ("epilogue", 4, 5), ("stores drained | binned", 5, 6), ("lifetime", 0, 6)):
     d = (st[:, b] - st[:, a]).astype(float)
     print("%-26s median %7.0f mean %7.0f p10 %7.0f p90 %7.0f ticks" % (nm, np.median(d), d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
-ts = np.arange(0, span, 20)
-act = ((st[:, 0][None, :] <= ts[:, None]) & (ts[:, None] < st[:, 6][None, :])).sum(1)
-drain = ((st[:, 5][None, :] <= ts[:, None]) & (ts[:, None] < st[:, 6][None, :])).sum(1)
-comp = ((st[:, 0][None, :] <= ts[:, None]) & (ts[:, None] < st[:, 5][None, :])).sum(1)
-print("time(us)  resident  computing  draining")
-for i in range(0, len(ts), max(1, len(ts) // 120)):
-    print("%7.1f %9d %9d %9d" % (ts[i] / 100.0, act[i], comp[i], drain[i]))
-mid = slice(len(ts) // 5, 4 * len(ts) // 5)
-print("middle 60%% of the span: draining workgroups mean %.0f, std %.0f, min %d, max %d" % (drain[mid].mean(), drain[mid].std(), drain[mid].min(), drain[mid].max()))
-# workgroups sharing a CU: start offsets of overlapping pairs
-offs = []
+print("lifetime by tile column (median):", " ".join("%d:%.0f" % (k, np.median(life[bx == k])) for k in range(ntx)))
+spans, resid, one, gaps = {}, [], [], []
 for c in np.unique(cu):
-    s = st[cu == c]
-    s = s[np.argsort(s[:, 0])]
-    for i in range(1, len(s)):
-        if s[i, 0] < s[i - 1, 6]:
-            offs.append((s[i, 0] - s[i - 1, 0]) / max(1.0, float(s[i - 1, 6] - s[i - 1, 0])))
-offs = np.array(offs)
-print("co-resident pairs %d: start offset / lifetime  median %.2f  p10 %.2f  p90 %.2f  (0 = lock step, 0.5 = alternating)"
-      % (len(offs), np.median(offs), np.percentile(offs, 10), np.percentile(offs, 90)))
-print("workgroups per CU: min %d max %d" % (np.bincount(np.unique(cu, return_inverse=True)[1]).min(), np.bincount(np.unique(cu, return_inverse=True)[1]).max()))
+    s_ = st[cu == c]
+    s_ = s_[np.argsort(s_[:, 0])]
+    t0, t1 = s_[0, 0], s_[:, 6].max()
+    spans[c] = t1 - t0
+    resid.append((s_[:, 6] - s_[:, 0]).sum() / float(t1 - t0))
+    ev = sorted([(a, 1) for a in s_[:, 0]] + [(b, -1) for b in s_[:, 6]])
+    n, last, acc = 0, t0, [0, 0, 0, 0]
+    for t, d in ev:
+        acc[min(n, 3)] += t - last
+        last = t
+        n += d
+    one.append((acc[0] + acc[1]) / float(t1 - t0))
+    ends = np.sort(s_[:, 6])
+    for i in range(2, len(s_)):                  # workgroup i takes the slot of the (i-2)th to finish
+        gaps.append(s_[i, 0] - ends[i - 2])
+sp = np.array(list(spans.values()), dtype=float)
+print("span of a CU (first start to last end): min %.0f median %.0f max %.0f ticks; the kernel lasts as long as the slowest" % (sp.min(), np.median(sp), sp.max()))
+for x in range(8):
+    v = np.array([spans[c] for c in spans if (c >> 16) == x], dtype=float)
+    print("   XCD %d: CUs %d, span median %.0f max %.0f" % (x, len(v), np.median(v), v.max()))
+print("resident workgroups per CU: mean %.2f; fraction of the span with fewer than two: %.2f" % (np.mean(resid), np.mean(one)))
+gaps = np.array(gaps, dtype=float)
+print("refill gap (a workgroup ends -> the next starts on that CU): median %.0f p90 %.0f ticks" % (np.median(gaps), np.percentile(gaps, 90)))
