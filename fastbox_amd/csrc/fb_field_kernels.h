@@ -727,11 +727,16 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
     const long long los = (long long)blockIdx.x * FB_RSD_WAVES + w;                 // N*N % WAVES == 0
     const T* d = delta + los * N;
     const T* v = vz + los * N;
-    for (int m = threadIdx.x; m < N; m += 64 * FB_RSD_WAVES) zg[m] = zgrid[m];
+    // LDS layout: cell c lives at index sw(c) = (c % E) 64 + c / E.  Lane l owns the E consecutive cells l E .. l E + E-1
+    // (one 16/32-byte global load each way), and nearly every LDS access of the kernel is "my e-th cell" or a cell a
+    // few places from it: stored in cell order those are 8 E bytes apart from lane to lane -- an E-way bank conflict on
+    // every one of the ~110 LDS instructions per line; transposed, lane l's e-th cell is word l of row e.
+    auto sw = [](int c) { return (c % E) * 64 + c / E; };
+    for (int m = threadIdx.x; m < N; m += 64 * FB_RSD_WAVES) zg[sw(m)] = zgrid[m];
 #pragma unroll
     for (int e = 0; e < E; ++e) kex[lane + 64 * e] = 0ull;
     __syncthreads();
-    const double zmin = zg[0], zmax = zg[N - 1];
+    const double zmin = zg[sw(0)], zmax = zg[sw(N - 1)];
     const double len = zmax - zmin;
     const double inv_dz = (double)(N - 1) / len;
     [[maybe_unused]] const double inv_Hz = 1.0 / Hz, inv_len = 1.0 / len;
@@ -778,12 +783,12 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         if constexpr (sizeof(T) == 4) {
             // single-precision plans: the inputs carry 1e-7 relative error, so reciprocals replace the two
             // fp64 divisions (displacement, wrap); the wrap still lands in [0, len)
-            const double a = (zg[m] - vel * inv_Hz) - zmin;
+            const double a = (zg[sw(m)] - vel * inv_Hz) - zmin;
             r = fma(-floor(a * inv_len), len, a);
             if (r < 0.0) r += len;
             if (r >= len) r -= len;
         } else {
-            const double s = zg[m] - vel / Hz;
+            const double s = zg[sw(m)] - vel / Hz;
             r = fmod_pos(s - zmin, len);              // numpy % : result takes the divisor's sign
             if (r != 0.0) { if (r < 0.0) r += len; } else r = 0.0;
         }
@@ -792,15 +797,15 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         c = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
         // settle on z_c <= key < z_{c+1}: the estimate is off by at most one cell, so one step down and
         // one step up without branches; the loops only run if that was not enough (never observed)
-        c -= (c > 0 && key < zg[c]) ? 1 : 0;
-        c += (c < N - 1 && key >= zg[c + 1]) ? 1 : 0;
-        if (__builtin_expect((c > 0 && key < zg[c]) || (c < N - 1 && key >= zg[c + 1]), 0)) {
-            for (int it = 0; it < N && c > 0 && key < zg[c]; ++it) --c;
-            for (int it = 0; it < N && c < N - 1 && key >= zg[c + 1]; ++it) ++c;
+        c -= (c > 0 && key < zg[sw(c)]) ? 1 : 0;
+        c += (c < N - 1 && key >= zg[sw(c + 1)]) ? 1 : 0;
+        if (__builtin_expect((c > 0 && key < zg[sw(c)]) || (c < N - 1 && key >= zg[sw(c + 1)]), 0)) {
+            for (int it = 0; it < N && c > 0 && key < zg[sw(c)]; ++it) --c;
+            for (int it = 0; it < N && c < N - 1 && key >= zg[sw(c + 1)]; ++it) ++c;
         }
         kb[e] = order_bits(key);
-        cell[e] = c;
-        atomicMax(&kex[c], kb[e]);
+        cell[e] = sw(c);                              // from here on the cell's LDS index
+        atomicMax(&kex[cell[e]], kb[e]);
     }
     rsd_wave_sync();
 #pragma unroll
@@ -813,7 +818,7 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
     int last = -1, first = N;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        cmx[e] = kex[lane * E + e];
+        cmx[e] = kex[lane + 64 * e];
         if (cmx[e] != 0ull) { last = lane * E + e; if (first == N) first = lane * E + e; }
     }
     int below = last, above = first;                  // inclusive scans over lanes: max from the left, min from the right
@@ -842,7 +847,7 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             rbv[e] = rb;
-            const int q = rb < 0 ? 0 : rb;
+            const int q = sw(rb < 0 ? 0 : rb);
             pk[e] = kex[q];
             pv[e] = vex[q];
             if (cmx[e] != 0ull) rb = lane * E + e;
@@ -864,7 +869,7 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
 #pragma unroll
     for (int e = 0; e < E; ++e) {
 #pragma clang fp contract(off)
-        const int c = lane * E + e;
+        const int c = lane + 64 * e;                   // LDS index of cell lane E + e
         const double x = zg[c];
         const bool filled = cmx[e] != 0ull;
         const int run_below = rbv[e];
@@ -874,7 +879,7 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
             // branch-free: bracket indices clamped into range, the three cases selected at the end
             const bool exact = filled && order_value(cmn_e) == x;
             const bool nofill = run_below >= 0 && ab[e] < N;
-            const int ra = ab[e] < N ? ab[e] : N - 1;
+            const int ra = sw(ab[e] < N ? ab[e] : N - 1);
             const double kj = order_value(pk[e]), kn = order_value(kex[ra]);
             const float vj = pv[e], vn = vex[ra];
             // differences in fp64 (close keys cancel), the quotient in fp32
@@ -887,7 +892,7 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
             else if (run_below < 0 || ab[e] >= N) y = fill;
             else {
                 const double kj = order_value(pk[e]), vj = (double)pv[e];
-                const double kn = order_value(kex[ab[e]]), vn = (double)vex[ab[e]];
+                const double kn = order_value(kex[sw(ab[e])]), vn = (double)vex[sw(ab[e])];
                 const double slope = (vn - vj) / (kn - kj);
                 y = slope * (x - kj) + vj;
                 if (y != y) {
