@@ -634,9 +634,9 @@ int fb_profile_select(fb_plan* p, unsigned mask) {
 int fb_profile_sample(fb_plan* p, int stride, int64_t* seen) {
     FB_REQUIRE(p, "null pointer");
     FB_USE_DEVICE(p);
-    FB_REQUIRE(stride >= 1, "stride must be >= 1");
+    FB_REQUIRE(stride >= 0, "stride must be >= 1, or 0 to read the count only");
     if (seen) *seen = (int64_t)p->prof_seen;
-    p->prof_stride = stride;
+    if (stride > 0) p->prof_stride = stride;
     return FB_OK;
 }
 int fb_profile_start(fb_plan* p) {

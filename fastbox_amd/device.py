@@ -601,7 +601,7 @@ class Engine(object):
     def profile_seen(self):
         """Selected launches since profile_start (bracketed or not)."""
         seen = ctypes.c_int64()
-        _lib.call("fb_profile_sample", self._plan, 1, ctypes.byref(seen))
+        _lib.call("fb_profile_sample", self._plan, 0, ctypes.byref(seen))       # 0: the sampling stride stays as it is
         return seen.value
 
     def profile_stop(self):

@@ -186,7 +186,8 @@ int fb_crop_full(fb_plan* plan, const void* full, void* half, void* stream);    
  * stop synchronises and returns summed milliseconds and launch counts per class above.  */
 int fb_profile_select(fb_plan* plan, unsigned mask);   /* bit i = bracket class i; default all */
 /* bracket only every stride-th selected launch (an event pair costs ~3 us of stream time; 1 = all, the default);
- * *seen (may be NULL) receives the number of selected launches since the last fb_profile_start */
+ * stride = 0 leaves the stride as it is; *seen (may be NULL) receives the number of selected launches since the last
+ * fb_profile_start */
 int fb_profile_sample(fb_plan* plan, int stride, int64_t* seen);
 int fb_profile_start(fb_plan* plan);
 int fb_profile_stop(fb_plan* plan, void* stream, double* ms, int64_t* launches, int ncat);
