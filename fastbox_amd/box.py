@@ -135,7 +135,8 @@ class FilteredField(DeviceArray):
     def __init__(self, engine, spectrum, filt, as_complex=True, parent=None):
         DeviceArray.__init__(self, engine, REAL, None, as_complex)
         self.spectrum, self.filter, self._parent = spectrum, filt, parent
-        self._filtered = None            # field_k * T once a fused P(k) has produced it
+        self._filtered = None            # field_k * T once a fused P(k) has produced it ...
+        self._x_done = None              # ... or that spectrum with its x lines already transformed back (see ptr)
 
     def _root(self):
         return self if self._parent is None else self._parent._root()
@@ -151,6 +152,10 @@ class FilteredField(DeviceArray):
             if root is not self:
                 root.ptr
                 self._buf = root._buf
+            elif self._x_done is not None:
+                # the fused P(k) pass took the inverse x transform of every line it filtered: y and z remain
+                self._buf = self.engine.fft_c2r_yz(self._x_done)._buf
+                self._x_done = None
             else:
                 dk = self._filtered if self._filtered is not None else \
                     self.engine.apply_filter(self.spectrum, self.filter.kind, self.filter.params)
@@ -593,9 +598,11 @@ class CosmoBox(object):
             # P(k) of apply_transfer_fn's result = shell sums of |field_k T|^2 (Hermitian field, even filter)
             root, src = delta_x._root(), delta_x.spectrum
             filt = (delta_x.filter.kind, delta_x.filter.params)
-            if root._filtered is None and not root.materialised and thr is not None \
+            if root._filtered is None and root._x_done is None and not root.materialised and thr is not None \
                     and isinstance(src, LazySpectrum) and src.source_real is not None and not src.materialised:
-                res, root._filtered = eng.power_filtered(src.source_real, filt)
+                # what apply_transfer_fn returns is the field (box.py:381): the pass that filters and bins an x line
+                # also transforms it back, and reading the field later costs the y and z passes only
+                res, root._x_done = eng.power_filtered(src.source_real, filt, field=True)
                 pending = PendingSpectrum(eng, res, bins.size, kc, self.boxfactor, None, None)
                 return pending if not wait else pending.result()
             if root._filtered is not None:

@@ -353,8 +353,22 @@ int fb_power_spectrum_filtered(fb_plan* p, const void* real_in, void* filtered_h
     FB_REQUIRE(p && real_in && filtered_half && results_dev, "null pointer");
     FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
-    return FB_DISPATCH(p, fbi_power_filtered_f32(p, real_in, filtered_half, kind, params, table_dev, (double*)results_dev, s),
-                       fbi_power_filtered_f64(p, real_in, filtered_half, kind, params, table_dev, (double*)results_dev, s));
+    return FB_DISPATCH(p, fbi_power_filtered_f32(p, real_in, filtered_half, kind, params, table_dev, (double*)results_dev, 0, s),
+                       fbi_power_filtered_f64(p, real_in, filtered_half, kind, params, table_dev, (double*)results_dev, 0, s));
+}
+int fb_power_spectrum_filtered_field(fb_plan* p, const void* real_in, void* work_half, int kind, const double* params,
+                                     const void* table_dev, void* results_dev, void* stream) {
+    FB_REQUIRE(p && real_in && work_half && results_dev, "null pointer");
+    FB_USE_DEVICE(p);
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_power_filtered_f32(p, real_in, work_half, kind, params, table_dev, (double*)results_dev, 1, s),
+                       fbi_power_filtered_f64(p, real_in, work_half, kind, params, table_dev, (double*)results_dev, 1, s));
+}
+int fb_fft_c2r_yz(fb_plan* p, void* half, void* out, double scale, void* stream) {
+    FB_REQUIRE(p && half && out, "null pointer");
+    FB_USE_DEVICE(p);
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_fft_c2r_yz_f32(p, half, out, scale, s), fbi_fft_c2r_yz_f64(p, half, out, scale, s));
 }
 int fb_power_spectrum_pending(fb_plan* p, void* pending_half, void* real_out, int pre_exp, double* results_dev,
                               void* stream) {

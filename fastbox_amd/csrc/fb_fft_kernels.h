@@ -494,6 +494,17 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                 }
             }
         }
+        [[maybe_unused]] T pq[E];                       // binning modes: |X|^2 of this thread's modes
+        if constexpr (smode_bins(MODE)) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) pq[e] = v[e].x * v[e].x + v[e].y * v[e].y;
+        }
+        if constexpr (MODE == SMODE_BINF) {
+            // store == 2: the caller wants the filtered FIELD (apply_transfer_fn's product, box.py:381): its inverse
+            // transform starts with this very x line, so it is taken here, on the registers that hold the filtered
+            // line, and the pass that would re-read and re-write the whole spectrum for it never runs
+            if (op.store == 2) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
+        }
         if constexpr (!smode_bins(MODE) || MODE == SMODE_BINF) {
             cx<T>* dst = a.out + ((long long)by * out_outer + bx * TZ) + tbase;
             const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
@@ -517,7 +528,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                 for (int e = 0; e < E; ++e) po[t + e * TPL] = v[e];
             }
 #pragma unroll
-            for (int e = 0; e < E; ++e) ptile[(t + e * TPL) * TZ + c] = v[e].x * v[e].x + v[e].y * v[e].y;
+            for (int e = 0; e < E; ++e) ptile[(t + e * TPL) * TZ + c] = pq[e];
             __syncthreads();
             FB_STAMP(5);
             double* row = acc + (size_t)(tid >> 6) * 2 * nb;

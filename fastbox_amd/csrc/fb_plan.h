@@ -120,7 +120,8 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_colour_noise_##sfx(fb_plan* p, const void* re, const void* im, void* out, hipStream_t s); \
     int fbi_colour_device_##sfx(fb_plan* p, uint64_t seed, uint64_t real, void* out, hipStream_t s); \
     int fbi_power_filtered_##sfx(fb_plan* p, const void* real_in, void* filtered_half, int kind, const double* prm, \
-                                 const void* table, double* results, hipStream_t s); \
+                                 const void* table, double* results, int inverse_x, hipStream_t s); \
+    int fbi_fft_c2r_yz_##sfx(fb_plan* p, void* half_inout, void* real_out, double scale, hipStream_t s); \
     int fbi_slab_forward_packed_##sfx(fb_plan* p, const void* real_local, void* half_local, void* xbuf, int nxl, \
                                       int nparts, int pre_exp, double* expsum, hipStream_t s); \
     int fbi_slab_inverse_packed_##sfx(fb_plan* p, const void* xbuf, void* half_local, void* real_local, int nxl, \

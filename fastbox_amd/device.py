@@ -517,15 +517,24 @@ class Engine(object):
                   1 if keep_spectrum else 0, res.ptr, self.stream)
         return res, (work if keep_spectrum else None)
 
-    def power_filtered(self, real, filt):
+    def power_filtered(self, real, filt, field=False):
         """Asynchronous r2c of `real` whose last pass multiplies by the filter (kind, params), keeps the
-        filtered spectrum and bins it.  Returns (results buffer, filtered half spectrum)."""
+        filtered spectrum and bins it.  Returns (results buffer, filtered half spectrum).  With ``field`` the last
+        pass also takes the inverse transform of every x line it has filtered: the buffer returned is then the
+        filtered spectrum half way back to the field, for `fft_c2r_yz` only."""
         res = self._result_slot()
         out = self.empty(HALF)
         prm = (ctypes.c_double * 4)(*[float(x) for x in filt[1]])
-        _lib.call("fb_power_spectrum_filtered", self._plan, real.ptr, out.ptr, int(filt[0]), prm, None, res.ptr,
-                  self.stream)
+        _lib.call("fb_power_spectrum_filtered_field" if field else "fb_power_spectrum_filtered", self._plan, real.ptr,
+                  out.ptr, int(filt[0]), prm, None, res.ptr, self.stream)
         return res, out
+
+    def fft_c2r_yz(self, half_x_done, as_complex=False):
+        """The y and z passes of `fft_c2r` (numpy's 1/N^3) for `power_filtered(..., field=True)`'s buffer, which is
+        destroyed."""
+        out = self.empty(REAL, as_complex)
+        _lib.call("fb_fft_c2r_yz", self._plan, half_x_done.ptr, out.ptr, 1.0 / self.N ** 3, self.stream)
+        return out
 
     RES_SLOTS, RES_STRIDE = 256, 2 * 256 + 1      # 256 = FB_MAX_BINS
 

@@ -125,6 +125,13 @@ int fb_bin_power_filtered(fb_plan* plan, const void* spec, int layout, int kind,
  * it.  Asynchronous; results_dev as for fb_power_spectrum_device.                              */
 int fb_power_spectrum_filtered(fb_plan* plan, const void* real_in, void* filtered_half, int kind,
                                const double* params, const void* table_dev, void* results_dev, void* stream);
+/* the same when what the caller goes on to read is the filtered FIELD (apply_transfer_fn's return value,
+ * box.py:381): the x pass that filters and bins a line also takes the line's inverse transform, so work_half
+ * receives the filtered spectrum already transformed back along x and fb_fft_c2r_yz (the y and z passes of
+ * fb_fft_c2r; work_half is destroyed) delivers the field -- one read and one write of the spectrum fewer.   */
+int fb_power_spectrum_filtered_field(fb_plan* plan, const void* real_in, void* work_half, int kind,
+                                     const double* params, const void* table_dev, void* results_dev, void* stream);
+int fb_fft_c2r_yz(fb_plan* plan, void* half_x_done, void* real_out, double scale, void* stream);
 
 /* fused path for cubic boxes (needs fb_set_bins with thr): r2c of real_in (of exp(real_in) when
  * pre_exp) with the binning inside the last pass.  Asynchronous: results_dev[2*nbins+1] (DEVICE)

@@ -219,8 +219,9 @@ def test_power_spectrum_of_filtered_field_without_transforms(prec, tol, scale):
 @pytest.mark.parametrize("N", [64, 256])
 def test_filter_and_power_spectrum_inside_the_forward_transform(prec, tol, N):
     """to_k(field) -> apply_transfer_fn -> binned_power_spectrum as ONE forward transform whose last pass
-    multiplies by T, stores the filtered spectrum and bins it (fb_power_spectrum_filtered); the filtered
-    field then comes from that stored spectrum.  Against the step-by-step route."""
+    multiplies by T, bins the filtered spectrum and takes the inverse transform of every x line it filtered
+    (fb_power_spectrum_filtered_field); the filtered field then needs the y and z passes only (fb_fft_c2r_yz), and
+    a second P(k) request falls back on the stand-alone route.  Against the step-by-step route."""
     from fastbox_amd import CosmoBox, default_cosmo, Wedge, BeamHighpass
     box = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False, precision=prec, rng="device", seed=6)
     dx = box.realise_density()
@@ -228,9 +229,12 @@ def test_filter_and_power_spectrum_inside_the_forward_transform(prec, tol, N):
     for filt in (Wedge(slope=0.3), BeamHighpass(kpar0=0.02, kperp0=0.3, power=2.)):
         lazy = box.apply_transfer_fn(box.to_k(dx), filt)
         pend = box.binned_power_spectrum(delta_x=lazy.real, nbins=20, wait=False)
-        assert lazy._filtered is not None and not lazy.materialised and not lazy.spectrum.materialised
+        assert lazy._x_done is not None and not lazy.materialised and not lazy.spectrum.materialised
         kc, pk, err = pend.result()
-        field = np.asarray(lazy.real)                                  # inverse of the stored filtered spectrum
+        again = box.binned_power_spectrum(delta_x=lazy.real, nbins=20)   # before the field has been read
+        assert np.array_equal(np.isnan(again[1]), np.isnan(pk)) and np.allclose(again[1][~np.isnan(pk)], pk[~np.isnan(pk)], rtol=10 * tol)
+        field = np.asarray(lazy.real)                                  # y and z passes of the half-way spectrum
+        assert lazy._x_done is None
         # step by step: explicit spectrum, separate filter kernel, inverse, P(k) of the resulting field
         slow = box.apply_transfer_fn(box.engine.fft_r2c(dx), filt)
         want_field = np.asarray(slow).real
