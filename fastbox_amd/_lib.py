@@ -106,6 +106,7 @@ SIGNATURES = {
     "fb_stream_create_priority": (c_int, [ctypes.POINTER(c_void_p), c_int]),
     "fb_stream_destroy": (c_int, [c_void_p]),
     "fb_stream_sync": (c_int, [c_void_p]),
+    "fb_stream_wait_stream": (c_int, [c_void_p, c_void_p]),
     "fb_device_count": (c_int, [ctypes.POINTER(c_int)]),
     "fb_device_set": (c_int, [c_int]),
 }

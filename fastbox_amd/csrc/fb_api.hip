@@ -728,5 +728,14 @@ int fb_stream_sync(void* stream) {
     FB_HIP(hipStreamSynchronize((hipStream_t)stream));
     return FB_OK;
 }
+int fb_stream_wait_stream(void* waiter, void* signaller) {
+    hipEvent_t ev;
+    FB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)signaller);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+    (void)hipEventDestroy(ev);      // released once the wait has been satisfied
+    FB_HIP(e);
+    return FB_OK;
+}
 
 }  // extern "C"

@@ -480,6 +480,12 @@ class Engine(object):
                   self.stream)
         return out
 
+    def wait_for(self, other):
+        """What is queued on this engine's stream from now on starts after everything queued on `other`'s stream so
+        far has finished (no host wait).  Two boxes sharing a GPU use it to keep their generator passes apart."""
+        _lib.call("fb_device_set", self.device)
+        _lib.call("fb_stream_wait_stream", self.stream, other.stream)
+
     def realise_begin(self, seed, realisation):
         """Generator + x pass; returns the pending half spectrum (y and z passes still to do)."""
         pend = self.empty(HALF)

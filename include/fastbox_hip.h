@@ -318,6 +318,9 @@ int fb_stream_create(void** stream);     /* a non-blocking hipStream_t, for runn
 int fb_stream_create_priority(void** stream, int priority);   /* priority < 0: the device's highest, 0: middle, > 0: lowest */
 int fb_stream_destroy(void* stream);
 int fb_stream_sync(void* stream);
+/* work queued on `waiter` after this call starts only when everything queued on `signaller` before it has finished
+ * (both streams on the current device); the host does not wait */
+int fb_stream_wait_stream(void* waiter, void* signaller);
 int fb_device_count(int* count);
 /* Make `device` the calling thread's current HIP device.  Every entry point that takes a plan does this for the plan's
  * device itself; bindings call it before the plan-less helpers above (fb_malloc, fb_stream_create) when they serve a

@@ -234,3 +234,22 @@ def test_spectrum_without_keeping_the_field(N):
             assert np.array_equal(x, y, equal_nan=True)
         fa, fb = np.asarray(da), np.asarray(db)                  # the second one is regenerated here
         assert db.materialised and np.array_equal(fa, fb)
+
+
+def test_one_box_waits_for_another_on_the_device():
+    """Engine.wait_for (fb_stream_wait_stream): box B's stream reads a field that box A's stream is still
+    producing -- ten queued realisations ahead of it -- without the host waiting in between."""
+    from fastbox_amd import CosmoBox, default_cosmo
+    from fastbox_amd.device import new_stream
+    N = 256
+    a = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False, precision="f64", rng="device", seed=21,
+                 stream=new_stream())
+    b = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False, precision="f64", rng="device", seed=22,
+                 stream=new_stream())
+    fields = [a.realise_density() for _ in range(10)]
+    for f in fields:
+        f.ptr                                          # queue every z pass on A's stream
+    b.engine.wait_for(a.engine)
+    got = b.engine.sum_real(fields[-1], squared=True)   # B's stream, A's buffer
+    want = float(np.sum(np.asarray(fields[-1]) ** 2))
+    assert abs(got - want) <= 1e-12 * want
