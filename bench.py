@@ -28,7 +28,7 @@ Prints ONE JSON line (see README / DESIGN.md for the fields).  Besides the contr
   sizes              N = 1: the same step at 256^3, 1024^3, 2048^3 on this GPU
   strong_scaling     N > 1: ONE box over all ranks (slab-decomposed FFT, RCCL all-to-all) at 1024^3 and 2048^3,
                      run as child jobs of rank 0 after the replicas leg (a failure there cannot take the line down)
-  cpu_baseline       the numpy oracle (the reference's algorithm) on one host core
+  cpu_baseline       the numpy oracle (the reference's algorithm) on one host core; threaded_fft_variant: the same with scipy.fft on all cores
 """
 import argparse
 import json
@@ -153,9 +153,26 @@ def cpu_baseline(nsamp_bench, nsamp_cpu, nbins):
     scale = (nsamp_bench / float(nsamp_cpu)) ** 3
     how = "the workload's own size, not scaled" if nsamp_cpu == nsamp_bench else \
         "scaled by voxel count x%.0f to %d^3" % (scale, nsamp_bench)
-    return {"value": 1.0 / (dt * scale), "unit": "boxes/s", "cores": 1, "kind": "port",
-            "sample": "one %d^3 realise_density + lognormal + binned_power_spectrum with the numpy oracle "
-                      "(%.1f s, 1 thread), %s" % (nsamp_cpu, dt, how)}
+    out = {"value": 1.0 / (dt * scale), "unit": "boxes/s", "cores": 1, "kind": "port",
+           "sample": "one %d^3 realise_density + lognormal + binned_power_spectrum with the numpy oracle "
+                     "(%.1f s, 1 thread), %s" % (nsamp_cpu, dt, how)}
+    try:        # SURVEY 8d's best-effort CPU line: the same step with its four 3-D FFTs on every core this job may use
+        cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+        rng = np.random.RandomState(1)
+        with bo.threaded_fft(cores) as tf:
+            t0 = time.time()
+            re, im = bo.draw_noise(nsamp_cpu, rng)
+            dx, dk = bo.realise_density(geo, standin.pk_fn(cosmo, 1.0), re, im)
+            ln = bo.lognormal(dx)
+            bo.binned_power_spectrum(geo, tf.fftn(ln), nbins=nbins)
+            dtt = time.time() - t0
+        out["threaded_fft_variant"] = {
+            "value": 1.0 / (dtt * scale), "unit": "boxes/s", "cores": cores,
+            "sample": "the same step with scipy.fft on %d threads (%.1f s): the reference's random draws and its binning "
+                      "loop stay on one core, as in fastbox/box.py" % (cores, dtt)}
+    except Exception as e:
+        out["threaded_fft_variant"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
 def _git_head():

@@ -19,8 +19,33 @@ Each function cites the reference lines it restates.  The arithmetic is kept
 in the reference's order of operations so that float64 results are identical,
 not merely close.
 """
+import contextlib
 import numpy as np
 from numpy import fft as _fft
+
+
+@contextlib.contextmanager
+def threaded_fft(workers):
+    """bench.py's best-effort CPU line: the same functions with scipy.fft on `workers` threads in place of
+    numpy's single-threaded pocketfft.  Results agree to rounding, not bit for bit: never used by a parity test."""
+    global _fft
+    import scipy.fft as sfft
+
+    class _Threaded(object):
+        fftfreq = staticmethod(np.fft.fftfreq)
+
+        @staticmethod
+        def fftn(a):
+            return sfft.fftn(a, workers=workers)
+
+        @staticmethod
+        def ifftn(a):
+            return sfft.ifftn(a, workers=workers)
+    keep, _fft = _fft, _Threaded
+    try:
+        yield _Threaded
+    finally:
+        _fft = keep
 
 
 # --------------------------------------------------------------------------
