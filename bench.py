@@ -231,6 +231,7 @@ def _make_boxes(args, N, precision, n, rank, local_rank):
     ps = args.plane_streams if args.plane_streams is not None else (0 if n == 1 else 1)
     for b in boxes:
         b.engine.set_plane_batching(pb, ps)
+        b._bench_plane_batching = (pb, ps)
     return boxes
 
 
@@ -417,6 +418,21 @@ def main():
             p.result()
         prof = eng.profile_stop()
         plain_launches = prof["fft_strided"][1]
+        # the same kernel in the launches one box per GPU would use (plane batches sized to the whole Infinity Cache:
+        # a launch carries a fixed fill and drain, so the larger launch reads closer to the kernel's own rate)
+        big = None
+        try:
+            eng.set_plane_batching(-1, 0)
+            one().result()
+            torch.cuda.synchronize()
+            eng.profile_start(["fft_strided"], stride=1)
+            for p in [one() for _ in range(20)]:
+                p.result()
+            pb_ = eng.profile_stop()["fft_strided"]
+            big = (pb_[0], pb_[1], 20)
+        finally:
+            eng.set_plane_batching(*boxes[0]._bench_plane_batching)
+            one().result()
     t_spin = time.perf_counter()
     spin_steps = 0
     while time.perf_counter() - t_spin < args.spin_up:
@@ -480,6 +496,14 @@ def main():
                              "on-die: this is L2 <-> fabric bandwidth; the whole-step figure (pipeline_roofline) is the HBM statement"},
         "from_profiles": fp,
     }
+    if not in_region and big and big[1]:
+        b_alg = 2 * (2.0 * N * N * ncols * 2 * s) * big[2] / big[1]
+        b_ach = b_alg / (big[0] / big[1] * 1e-3) / 1e9
+        line["roofline"]["one_box_launch"] = {
+            "what": "the same kernel, same un-overlapped method, in the larger launches one box per GPU uses (plane "
+                    "batches sized to the whole Infinity Cache)",
+            "algorithmic_bytes": b_alg, "avg_launch_us": 1e3 * big[0] / big[1], "launches_timed": big[1],
+            "achieved": b_ach, "frac": b_ach / HBM_PEAK_GBS}
     if in_region:
         total_ms = sum(v[0] for v in prof.values()) * (plain_launches / max(launches, 1) if ev_stride > 1 else 1.)
         line["kernel_ms_per_step"] = {k: round(v[0] / args.steps * (plain_launches / max(v[1], 1) if ev_stride > 1 else 1.), 4)
