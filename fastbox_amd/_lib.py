@@ -47,7 +47,7 @@ SIGNATURES = {
     "fb_potential_k": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fb_lognormal": (c_int, [c_void_p, c_void_p, c_void_p, P_double, c_void_p]),
     "fb_redshift_space": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_u64,
-                                  c_void_p]),
+                                  c_int, c_void_p]),
     "fb_sum_real": (c_int, [c_void_p, c_void_p, c_int, P_double, c_void_p]),
     "fb_sumsq_half": (c_int, [c_void_p, c_void_p, P_double, c_void_p]),
     "fb_expand_half": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -279,14 +279,15 @@ int fb_lognormal(fb_plan* p, const void* in, void* out, double* mean_out, void* 
     return FB_DISPATCH(p, fbi_lognormal_f32(p, in, out, mean_out, s), fbi_lognormal_f64(p, in, out, mean_out, s));
 }
 int fb_redshift_space(fb_plan* p, const void* delta, const void* vz, const void* noise, void* out, double Hz,
-                      double sigma_nl, uint64_t seed, void* stream) {
+                      double sigma_nl, uint64_t seed, int method, void* stream) {
     FB_REQUIRE(p && delta && vz && out, "null pointer");
     FB_USE_DEVICE(p);
     FB_REQUIRE(Hz > 0, "Hz must be positive");
     FB_REQUIRE(out != delta && out != vz, "redshift_space is out of place");
+    FB_REQUIRE(method == FB_RSD_LINEAR || method == FB_RSD_NEAREST, "method: FB_RSD_LINEAR or FB_RSD_NEAREST");
     hipStream_t s = (hipStream_t)stream;
-    return FB_DISPATCH(p, fbi_rsd_f32(p, delta, vz, noise, out, Hz, sigma_nl, seed, s),
-                       fbi_rsd_f64(p, delta, vz, noise, out, Hz, sigma_nl, seed, s));
+    return FB_DISPATCH(p, fbi_rsd_f32(p, delta, vz, noise, out, Hz, sigma_nl, seed, method, s),
+                       fbi_rsd_f64(p, delta, vz, noise, out, Hz, sigma_nl, seed, method, s));
 }
 int fb_sum_real(fb_plan* p, const void* x, int squared, double* out, void* stream) {
     FB_REQUIRE(p && x && out, "null pointer");

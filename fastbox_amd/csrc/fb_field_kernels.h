@@ -614,7 +614,7 @@ __global__ void k_slab_permute(const uint4* __restrict__ in, uint4* __restrict__
 template <typename T>
 __global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise,
                       T* __restrict__ out, const double* __restrict__ zgrid, int N, double Hz, double sigma_nl,
-                      RngKey rkey) {
+                      RngKey rkey, int nearest) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* key = reinterpret_cast<double*>(smem);   // [N]
     double* val = key + N;                            // [N]
@@ -656,7 +656,15 @@ __global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, con
 #pragma clang fp contract(off)
         const double x = zgrid[m];
         double y;
-        if (x < key[0] || x > key[N - 1]) y = fill;
+        if (nearest) {
+            // griddata(method='nearest') in 1-D = interp1d(kind='nearest', fill_value='extrapolate'): the key whose
+            // neighbourhood, bounded by the midpoints k_a/2 + k_b/2, holds x; a midpoint itself goes to the lower key
+            int lo = 0, hi = N;                        // count of key[] <= x
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[mid] <= x) lo = mid + 1; else hi = mid; }
+            if (lo == 0) y = val[0];
+            else if (lo == N) y = val[N - 1];
+            else y = (key[lo - 1] * 0.5 + key[lo] * 0.5 < x) ? val[lo] : val[lo - 1];
+        } else if (x < key[0] || x > key[N - 1]) y = fill;
         else {
             int lo = 0, hi = N;                        // count of key[] <= x
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[mid] <= x) lo = mid + 1; else hi = mid; }
@@ -713,7 +721,7 @@ __device__ __forceinline__ void rsd_wave_sync() {
 template <typename T, int E>
 __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise, T* __restrict__ out,
-        const double* __restrict__ zgrid, double Hz, double sigma_nl, RngKey rkey) {
+        const double* __restrict__ zgrid, double Hz, double sigma_nl, RngKey rkey, int nearest) {
     constexpr int N = E * 64;
     typedef unsigned long long u64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -887,9 +895,15 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
             float yi = vj + (vn - vj) * w;
             yi = (yi != yi && vj == vn) ? vj : yi;
             y = exact ? (double)vex[c] : (nofill ? (double)yi : fill);
+            if (nearest && !exact)                    // see k_rsd: the nearer bracket, the lower one on a midpoint
+                y = (run_below < 0) ? (double)vn : ((ab[e] >= N) ? (double)vj : ((kj * 0.5 + kn * 0.5 < x) ? (double)vn : (double)vj));
         } else {
             if (filled && order_value(cmn_e) == x) y = (double)vex[c];
-            else if (run_below < 0 || ab[e] >= N) y = fill;
+            else if (nearest) {
+                const int qa = sw(ab[e] < N ? ab[e] : N - 1);
+                const double kj = order_value(pk[e]), kn = order_value(kex[qa]);
+                y = (run_below < 0) ? (double)vex[qa] : ((ab[e] >= N) ? (double)pv[e] : ((kj * 0.5 + kn * 0.5 < x) ? (double)vex[qa] : (double)pv[e]));
+            } else if (run_below < 0 || ab[e] >= N) y = fill;
             else {
                 const double kj = order_value(pk[e]), vj = (double)pv[e];
                 const double kn = order_value(kex[sw(ab[e])]), vn = (double)vex[sw(ab[e])];

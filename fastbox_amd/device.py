@@ -452,10 +452,12 @@ class Engine(object):
         _lib.call("fb_lognormal", self._plan, real.ptr, out.ptr, ctypes.byref(mean), self.stream)
         return out, mean.value
 
-    def redshift_space(self, delta, vz, Hz, sigma_nl=0.0, noise=None, seed=0):
+    RSD_METHODS = {"linear": 0, "nearest": 1}       # FB_RSD_LINEAR, FB_RSD_NEAREST
+
+    def redshift_space(self, delta, vz, Hz, sigma_nl=0.0, noise=None, seed=0, method="linear"):
         out = self.empty(REAL)
         _lib.call("fb_redshift_space", self._plan, delta.ptr, vz.ptr, noise.ptr if noise is not None else None,
-                  out.ptr, float(Hz), float(sigma_nl), int(seed) & (2 ** 64 - 1), self.stream)
+                  out.ptr, float(Hz), float(sigma_nl), int(seed) & (2 ** 64 - 1), self.RSD_METHODS[method], self.stream)
         return out
 
     # -- fused throughput path -------------------------------------------------------------

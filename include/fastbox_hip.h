@@ -164,9 +164,13 @@ int fb_potential_k(fb_plan* plan, const void* dk, void* out, int layout, void* s
 /* out = exp(in)/mean(exp(in)) - 1 (box.py:457-460); *mean_out receives mean(exp(in)). Synchronises. */
 int fb_lognormal(fb_plan* plan, const void* real_in, void* real_out, double* mean_out, void* stream);
 /* redshift_space_density (box.py:405-437). noise: T[N][N][N] standard normals in LOS order
- * (parity) or NULL -> Philox stream 1 of `seed` when sigma_nl > 0.                                          */
+ * (parity) or NULL -> Philox stream 1 of `seed` when sigma_nl > 0.  method: what box.py:433-437 hands to
+ * scipy's griddata -- 'linear' (the default; points outside the shifted samples get the end-point average)
+ * or 'nearest' (no fill: scipy extrapolates with the end samples).                                        */
+#define FB_RSD_LINEAR 0
+#define FB_RSD_NEAREST 1
 int fb_redshift_space(fb_plan* plan, const void* delta, const void* vz, const void* noise, void* out,
-                      double Hz, double sigma_nl, uint64_t seed, void* stream);
+                      double Hz, double sigma_nl, uint64_t seed, int method, void* stream);
 /* sum(x) / sum(x^2) over a real field; sum |dk|^2 over the FULL grid from a half spectrum
  * (test_parseval, box.py:944-946).  Synchronise.                                                    */
 int fb_sum_real(fb_plan* plan, const void* real, int squared, double* out, void* stream);

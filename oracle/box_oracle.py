@@ -294,11 +294,24 @@ def _regrid_linear_1d(s, vals, zgrid, fill):
     return out
 
 
+def _regrid_nearest_1d(s, values, xi):
+    """griddata(points, values, xi, method='nearest') for 1-D points (scipy 1.15 _ndgriddata.py:303-317: argsort, then
+    interp1d(kind='nearest', fill_value='extrapolate'); _interpolate.py: x_bds = x/2, x_bds[1:] + x_bds[:-1];
+    searchsorted(x_bds, x_new, side='left'), clipped): the sample whose neighbourhood between midpoints holds x_new,
+    the lower one when x_new is a midpoint; beyond the end samples, the end samples (no fill value)."""
+    idx = np.argsort(s)
+    x, y = s[idx], values[idx]
+    x_bds = x / 2.0
+    x_bds = x_bds[1:] + x_bds[:-1]
+    k = np.searchsorted(x_bds, xi, side='left').clip(0, len(x) - 1)
+    return y[k]
+
+
 def redshift_space_density(g, delta_x, velocity_z, Hz, sigma_nl=0.,
-                           rng=np.random):
+                           rng=np.random, method='linear'):
     """Per line of sight (i,j): s = z - (v_z + sigma_nl n)/H, periodic wrap,
     re-grid delta(s) on z; endpoint-average fill.  Noise is drawn LOS by LOS in
-    (i,j) order from the legacy global stream (box.py:412-418)."""
+    (i,j) order from the legacy global stream (box.py:412-418).  method: 'linear' or 'nearest' (box.py:433-437)."""
     z = g['z']
     out = np.zeros_like(delta_x) - 1.
     zmin = np.min(z)
@@ -311,7 +324,10 @@ def redshift_space_density(g, delta_x, velocity_z, Hz, sigma_nl=0.,
             s = z - (velocity_z[i, j, :] + vel_nl) / Hz
             s = (s - zmin) % length_z + zmin
             fill = 0.5 * (delta_x[i, j, 0] + delta_x[i, j, -1])
-            out[i, j, :] = _regrid_linear_1d(s, delta_x[i, j, :], z, fill)
+            if method == 'nearest':
+                out[i, j, :] = _regrid_nearest_1d(s, delta_x[i, j, :], z)
+            else:
+                out[i, j, :] = _regrid_linear_1d(s, delta_x[i, j, :], z, fill)
     return out
 
 

@@ -127,6 +127,9 @@ def capture(ref, name, N, box_scale, redshift, seed, s, what):
         fw = box.apply_transfer_fn(np.fft.fftn(rs), standin.wedge03)
         out["rsd_wedge"] = probe(fw, s)
         out["pkrsdw_k"], out["pkrsdw_p"], out["pkrsdw_e"] = box.binned_power_spectrum(delta_x=fw.real)
+        # the other regridding rule box.py:433-437 accepts (sigma_nl = 0: no draw, the stream stays where it is)
+        out["rsd0_nearest"] = probe(box.redshift_space_density(delta_x=box.delta_x, velocity_z=vz, sigma_nl=0.,
+                                                               method='nearest'), s)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("wrote", name, "(%d arrays)" % len(out))
 

@@ -153,6 +153,10 @@ def test_redshift_space_fp64(golden_dir, name):
     assert _field_close(p(rsd0), g["rsd0"], 1e-9)
     rsd200 = box.redshift_space_density(delta_x=dx, velocity_z=vz, sigma_nl=200., method='linear')
     assert _field_close(p(rsd200), g["rsd200"], 1e-9)
+    near = box.redshift_space_density(delta_x=dx, velocity_z=vz, sigma_nl=0., method='nearest')   # box.py:433-437
+    assert _field_close(p(near), g["rsd0_nearest"], 1e-9)
+    with pytest.raises(NotImplementedError):
+        box.redshift_space_density(delta_x=dx, velocity_z=vz, method='cubic')
     kc, pk, err = box.binned_power_spectrum(delta_x=rsd0)
     assert _pk_close((pk,), (g["pkrsd_p"],), 1e-9)
     # BASELINE configs[2]: the wedge-filtered redshift-space field and its P(k), fused route (filter and binning inside
@@ -183,6 +187,22 @@ def test_redshift_space_cells_per_lane(N, vscale):
     want = bo.redshift_space_density(geo, d, v, Hz, 0.)
     got = np.asarray(box.redshift_space_density(delta_x=d, velocity_z=v, sigma_nl=0.))
     assert np.max(np.abs(got - want)) < 1e-12 * np.max(np.abs(want))
+    # method='nearest' copies one sample per grid point: exact, save where a grid point lies within rounding of
+    # the midpoint of its two brackets
+    got = np.asarray(box.redshift_space_density(delta_x=d, velocity_z=v, sigma_nl=0., method='nearest'))
+    if vscale == 0.:
+        # every sample stays on its grid point, and the last one wraps onto the first: two samples with EQUAL keys, of
+        # which scipy returns whichever its (unstable) argsort happens to put first -- either is right there
+        assert np.array_equal(got[:, :, 1:-1], d[:, :, 1:-1])
+        assert np.all((got[:, :, 0] == d[:, :, 0]) | (got[:, :, 0] == d[:, :, -1]))
+        return
+    want = bo.redshift_space_density(geo, d, v, Hz, 0., method='nearest')
+    assert np.mean(got != want) < 1e-6
+    box32 = CosmoBox(cosmo=default_cosmo, box_scale=3e2, nsamp=N, realise_now=False, precision="f32")
+    d32, v32 = d.astype(np.float32).astype(np.float64), v.astype(np.float32).astype(np.float64)
+    want = bo.redshift_space_density(geo, d32, v32, Hz, 0., method='nearest')
+    got = np.asarray(box32.redshift_space_density(delta_x=d32, velocity_z=v32, sigma_nl=0., method='nearest'))
+    assert np.mean(got != want.astype(np.float32)) < 1e-5
 
 
 @pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("f64", 1e-10)])
@@ -337,6 +357,9 @@ def test_redshift_space_kernel_exact_on_same_inputs(N):
     got = box.redshift_space_density(delta_x=d, velocity_z=v, sigma_nl=150.)
     want = bo.redshift_space_density(geo, d, v, Hz, 150., np.random.RandomState(9))
     assert np.max(np.abs(np.asarray(got) - want)) < 1e-12 * np.max(np.abs(want))
+    want = bo.redshift_space_density(geo, d, v, Hz, 0., method='nearest')       # N = 16: the sorting kernel
+    got = np.asarray(box.redshift_space_density(delta_x=d, velocity_z=v, sigma_nl=0., method='nearest'))
+    assert np.mean(got != want) < 1e-4
 
 
 def test_reference_unit_tests_behaviour():

@@ -100,6 +100,7 @@ def test_derived_fields(golden_dir, name):
     assert _same(p(fw), g["rsd_wedge"])
     kc, pk, err = bo.binned_power_spectrum(geo, np.fft.fftn(fw.real))
     assert _same(kc, g["pkrsdw_k"]) and _same(pk, g["pkrsdw_p"]) and _same(err, g["pkrsdw_e"])
+    assert _same(p(bo.redshift_space_density(geo, dx, vz, Hz, 0., method='nearest')), g["rsd0_nearest"])
 
 
 @pytest.mark.skipif(os.environ.get("FASTBOX_SLOW_TESTS", "0") != "1",
