@@ -439,6 +439,9 @@ def main():
         _warm(step, 10)
         spin_steps += 10
     _warm(step, max(args.warmup, len(boxes)))
+    import gc
+    gc.collect()
+    gc.disable()                          # a collector pause inside a 20 ms timed region would be 5 % of it
     fence()
     if in_region:
         eng.profile_start(None if args.all_kernel_events else ["fft_strided"], stride=ev_stride)
@@ -453,6 +456,7 @@ def main():
         plain_launches = eng.profile_seen() if ev_stride > 1 else prof["fft_strided"][1]
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=args._reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
