@@ -448,7 +448,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 #endif
         if constexpr (PERSIST) __syncthreads();   // LDS of the previous tile's epilogue is free again
         else load_tables();
-        if constexpr (smode_bins(MODE) && (64 * E) % TZ == 0 && (N / 2) % ((64 * E) / TZ) == 0 && TZ % E == 0) {
+        if constexpr (smode_bins(MODE) && (64 * E) % TZ == 0 && (N / 2) % ((64 * E) / TZ) == 0 && (TZ % E == 0 || E % TZ == 0)) {
             // The bins of this wave's block of the tile depend on the tile's coordinates only: look
             // them up now, while the tile's data is still on its way from HBM.
             constexpr int RW = (64 * E) / TZ;
@@ -543,18 +543,29 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             // then splits its E modes at that edge, four wave reductions finish the job.  Weights: a
             // stored mode counts twice except on the k_z = 0, N/2 planes; padding columns count 0.
             bool done = false;
-            if constexpr ((64 * E) % TZ == 0 && (N / 2) % ((64 * E) / TZ) == 0 && TZ % E == 0) {
+            if constexpr ((64 * E) % TZ == 0 && (N / 2) % ((64 * E) / TZ) == 0 && (TZ % E == 0 || E % TZ == 0)) {
                 const int blo = wb_lo, bhi = wb_hi, edge = wb_edge;
                 const int mx = mode_of(off0 / TZ, N);
                 const int n2row = mx * mx + my2;
                 const int kz0 = col0 + off0 % TZ;
+                // a lane's E consecutive elements: part of one k_x row (E <= TZ), or E / TZ whole rows (16 points per
+                // thread at N = 2048: two rows of 8 columns) -- row and column of element q are then compile-time offsets
+                auto n2row_of = [&](int q) -> int {
+                    if constexpr (E <= TZ) return n2row;
+                    else { const int m = mode_of(off0 / TZ + q / TZ, N); return m * m + my2; }
+                };
+                auto kz_of = [&](int q) -> int {
+                    if constexpr (E <= TZ) return kz0 + q;
+                    else return col0 + q % TZ;
+                };
                 bool exact = false;                // does a mode of this wave sit ON one of the edge-shells?
                 if (wb_ok && wb_rng) {
                     bool mine = false;
 #pragma unroll
                     for (int q = 0; q < E; ++q) {
-                        const int n2 = n2row + (kz0 + q) * (kz0 + q);
-                        for (int z = 0; z < op.namb; ++z) mine |= (op.amb[z] == n2) && (kz0 + q < a.ncols) && !(pk0 && kz0 + q == 0);
+                        const int kzq = kz_of(q);
+                        const int n2 = n2row_of(q) + kzq * kzq;
+                        for (int z = 0; z < op.namb; ++z) mine |= (op.amb[z] == n2) && (kzq < a.ncols) && !(pk0 && kzq == 0);
                     }
                     exact = __any(mine);
                 }
@@ -570,9 +581,9 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     } else if (inner) {
 #pragma unroll
                         for (int q = 0; q < E; ++q) {
-                            const int kz = kz0 + q;
+                            const int kz = kz_of(q);
                             const T p = ptile[off0 + q], p2 = p * p;
-                            const bool up = n2row + kz * kz >= edge;
+                            const bool up = n2row_of(q) + kz * kz >= edge;
                             s1 += up ? (T)0 : p; s2 += up ? (T)0 : p2;
                             u1 += up ? p : (T)0; u2 += up ? p2 : (T)0;
                         }
@@ -580,11 +591,11 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     } else {
 #pragma unroll
                         for (int q = 0; q < E; ++q) {
-                            const int kz = kz0 + q;
+                            const int kz = kz_of(q);
                             T p = ptile[off0 + q];
                             p = (kz >= a.ncols || (pk0 && kz == 0)) ? (T)0 : ((kz == 0 || kz == (N >> 1)) ? p : (T)2 * p);   // weight in p
                             const T p2 = (kz == 0 || kz == (N >> 1)) ? p * p : (T)0.5 * p * p;            // w p^2
-                            const bool up = n2row + kz * kz >= edge;
+                            const bool up = n2row_of(q) + kz * kz >= edge;
                             s1 += up ? (T)0 : p; s2 += up ? (T)0 : p2;
                             u1 += up ? p : (T)0; u2 += up ? p2 : (T)0;
                         }
