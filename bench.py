@@ -433,15 +433,15 @@ def main():
         finally:
             eng.set_plane_batching(*boxes[0]._bench_plane_batching)
             one().result()
+    import gc
+    gc.collect()                          # BEFORE the spin-up: an idle gap directly before the timed region would let the
+    gc.disable()                          # clocks drop again; a collector pause inside a 20 ms region would be 5 % of it
     t_spin = time.perf_counter()
     spin_steps = 0
     while time.perf_counter() - t_spin < args.spin_up:
         _warm(step, 10)
         spin_steps += 10
     _warm(step, max(args.warmup, len(boxes)))
-    import gc
-    gc.collect()
-    gc.disable()                          # a collector pause inside a 20 ms timed region would be 5 % of it
     fence()
     if in_region:
         eng.profile_start(None if args.all_kernel_events else ["fft_strided"], stride=ev_stride)
