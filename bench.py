@@ -396,8 +396,8 @@ def main():
                 out = {}
                 for n2 in [int(x) for x in args.sizes.split(",") if x]:
                     if n2 != N:
-                        st = max(3, min(100, int(100 * (256. / n2) ** 3)))
-                        out[str(n2)] = quick_rate(args, n2, args.precision, st, 2, rank, local_rank, torch)
+                        st = max(8, min(100, int(100 * (256. / n2) ** 3)))     # >= 4 steps per box of a two-box run
+                        out[str(n2)] = quick_rate(args, n2, args.precision, st, 4, rank, local_rank, torch)
                 return out
             guarded("sizes", sizes)
     if world > 1:
