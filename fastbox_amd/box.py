@@ -129,14 +129,15 @@ class FilteredField(DeviceArray):
     """ifftn(field_k * T(k_perp, k_par)) for a Hermitian device spectrum and a k_par-even ``DeviceFilter``
     (apply_transfer_fn, box.py:356-381), formed when it is first read.  ``binned_power_spectrum`` of it
     (or of its ``.real``) needs no transform of its own: it bins |field_k T|^2 from ``field_k``; when
-    ``field_k`` is itself a pending ``CosmoBox.to_k(field)``, the multiply, the binning and the store of the
-    filtered spectrum all happen inside the last pass of that forward transform."""
+    ``field_k`` is itself a pending ``CosmoBox.to_k(field)``, the multiply and the binning happen inside the last (x)
+    pass of that forward transform, which also takes the inverse transform of each x line it has filtered -- reading
+    the field afterwards costs the y and z passes only."""
 
     def __init__(self, engine, spectrum, filt, as_complex=True, parent=None):
         DeviceArray.__init__(self, engine, REAL, None, as_complex)
         self.spectrum, self.filter, self._parent = spectrum, filt, parent
-        self._filtered = None            # field_k * T once a fused P(k) has produced it ...
-        self._x_done = None              # ... or that spectrum with its x lines already transformed back (see ptr)
+        self._x_done = None              # field_k * T with its x lines already transformed back, once a fused P(k) has
+                                         # produced it (see ptr)
 
     def _root(self):
         return self if self._parent is None else self._parent._root()
@@ -157,9 +158,7 @@ class FilteredField(DeviceArray):
                 self._buf = self.engine.fft_c2r_yz(self._x_done)._buf
                 self._x_done = None
             else:
-                dk = self._filtered if self._filtered is not None else \
-                    self.engine.apply_filter(self.spectrum, self.filter.kind, self.filter.params)
-                self._filtered = None
+                dk = self.engine.apply_filter(self.spectrum, self.filter.kind, self.filter.params)
                 self._buf = self.engine.fft_c2r(dk, destroy=True)._buf
         return self._buf.ptr
 
@@ -600,17 +599,14 @@ class CosmoBox(object):
             # P(k) of apply_transfer_fn's result = shell sums of |field_k T|^2 (Hermitian field, even filter)
             root, src = delta_x._root(), delta_x.spectrum
             filt = (delta_x.filter.kind, delta_x.filter.params)
-            if root._filtered is None and root._x_done is None and not root.materialised and thr is not None \
+            if root._x_done is None and not root.materialised and thr is not None \
                     and isinstance(src, LazySpectrum) and src.source_real is not None and not src.materialised:
                 # what apply_transfer_fn returns is the field (box.py:381): the pass that filters and bins an x line
                 # also transforms it back, and reading the field later costs the y and z passes only
                 res, root._x_done = eng.power_filtered(src.source_real, filt, field=True)
                 pending = PendingSpectrum(eng, res, bins.size, kc, self.boxfactor, None, None)
                 return pending if not wait else pending.result()
-            if root._filtered is not None:
-                cnt, s1, s2 = eng.bin_power(root._filtered)
-            else:
-                cnt, s1, s2 = eng.bin_power(src, filt=filt)
+            cnt, s1, s2 = eng.bin_power(src, filt=filt)
             out = (kc,) + _finish_bins(cnt, s1, s2, self.boxfactor, _eps_of(eng))
             return out if wait else _Ready(out)
 

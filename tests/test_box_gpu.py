@@ -264,6 +264,11 @@ def test_filter_and_power_spectrum_inside_the_forward_transform(prec, tol, N):
         assert np.array_equal(kc, kc2) and np.array_equal(np.isnan(pk), np.isnan(pk2))
         assert np.allclose(pk[m], pk2[m], rtol=tol, atol=tol * np.max(pk2[m]) * 1e-6)
         assert np.allclose(err[m], err2[m], rtol=100 * tol, atol=tol * np.max(pk2[m]))
+        # the C ABI's other form (fb_power_spectrum_filtered): the filtered SPECTRUM is kept, fb_fft_c2r finishes it
+        eng = box.engine
+        res, half = eng.power_filtered(box._as_real(dx), (filt.kind, filt.params))
+        field2 = np.asarray(eng.fft_c2r(half, destroy=True))
+        assert np.max(np.abs(field2 - want_field)) < 20 * tol * np.std(want_field)
 
 
 @pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("f64", 1e-10)])
