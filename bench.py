@@ -74,6 +74,8 @@ def parse(argv=None):
                     help="x-planes per cache-resident batch of the y/z passes (default: the library's size for one box per "
                          "GPU when --streams 1, N/8 when several boxes share the GPU)")
     ap.add_argument("--plane-streams", type=int, default=None, help="1 | 2 streams for alternate plane batches")
+    ap.add_argument("--no-one-box-pass", action="store_true",
+                    help="skip roofline.one_box_launch (profiler runs: keeps every launch of the roofline kernel the same size)")
     ap.add_argument("--gaussian-only", action="store_true",
                     help="tuning aid: P(k) of the Gaussian field itself (no exp in the fused z pass); the line is then NOT "
                          "BASELINE's configs[1]")
@@ -429,6 +431,8 @@ def main():
         # a launch carries a fixed fill and drain, so the larger launch reads closer to the kernel's own rate)
         big = None
         try:
+            if args.no_one_box_pass:
+                raise StopIteration
             eng.set_plane_batching(-1, 0)
             one().result()
             torch.cuda.synchronize()
@@ -437,6 +441,8 @@ def main():
                 p.result()
             pb_ = eng.profile_stop()["fft_strided"]
             big = (pb_[0], pb_[1], 20)
+        except StopIteration:
+            pass
         finally:
             eng.set_plane_batching(*boxes[0]._bench_plane_batching)
             one().result()

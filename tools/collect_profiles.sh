@@ -17,7 +17,7 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -- python3 $R/bench.py $ARGS --streams 1 > $OUT/bench_streams1_under_rocprof.json 2> $OUT/trace1.err
 cp $(ls $OUT/trace1/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_streams1.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -- python3 $R/bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -- python3 $R/bench.py $ARGS --no-one-box-pass > $OUT/bench_under_rocprof.json 2> $OUT/trace2.err
 cp $(ls $OUT/trace2/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 # the launches of the default command's roofline pass, every kernel alone: one box, the 64-plane batches of the two-box run
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace3 -- python3 $R/bench.py $ARGS --streams 1 --plane-batch 64 > $OUT/bench_streams1_pb64_under_rocprof.json 2> $OUT/trace3.err
@@ -25,7 +25,7 @@ cp $(ls $OUT/trace3/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_streams1_pb
 for C in FETCH_SIZE WRITE_SIZE; do
     # the default command (two boxes, 64-plane batches at 512^3): the counters are per dispatch, and the profiler runs
     # the dispatches of a counter pass one at a time
-    rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS --spin-up 0 --steps 10 --warmup 2 > /dev/null 2> $OUT/pmc_$C.err
+    rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS --no-one-box-pass --spin-up 0 --steps 10 --warmup 2 > /dev/null 2> $OUT/pmc_$C.err
 done
 python3 $R/tools/pmc_summary.py $OUT/pmc_fetch_write_summary.json $(ls $OUT/pmc_*/*/*counter_collection.csv) > $OUT/pmc_summary.txt
 rm -rf $OUT/trace1 $OUT/trace2 $OUT/trace3 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
