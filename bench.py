@@ -249,13 +249,28 @@ def _step_fn(boxes, nbins, lognormal=True, keep_field=True):
     return step
 
 
+def _check_finite(triples, what):
+    """Every (kc, pk, stddev) of a leg: finite on the bins that hold modes, the same empty-bin mask throughout.
+    A leg that timed garbage raises instead of reporting a rate; returns the number of spectra checked."""
+    import numpy as np
+    mask = None
+    for kc, pk, err in triples:
+        empty = np.isnan(pk)
+        if mask is None:
+            mask = empty
+        if not np.array_equal(empty, mask) or not np.all(np.isfinite(pk[~empty])) or not np.all(np.isfinite(err[~empty])) \
+                or not np.all(np.isfinite(kc)) or empty.all():
+            raise FloatingPointError("%s: non-finite power spectrum %r" % (what, pk))
+    return len(triples)
+
+
 def _warm(step, n):
     """n untimed steps, queued back to back like the timed ones (the GPU stays busy up to the fence)."""
     for p in [step() for _ in range(n)]:
         p.result()
 
 
-def _timed_steps(step, steps, warmup, sync, spin_s=0.1):
+def _timed_steps(step, steps, warmup, sync, spin_s=0.1, what="leg"):
     # the legs start from an idle GPU (plans were just created): untimed steps until the clocks are up
     # (profiles/r02_step_timeline.txt: ~40-60 steps of the 512^3 workload after an idle gap)
     t_spin = time.perf_counter()
@@ -265,10 +280,11 @@ def _timed_steps(step, steps, warmup, sync, spin_s=0.1):
     sync()
     t0 = time.perf_counter()
     pend = [step() for _ in range(steps)]
-    for p in pend:
-        p.result()
+    out = [p.result() for p in pend]
     sync()
-    return time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    _check_finite(out, what)
+    return dt
 
 
 def quick_rate(args, N, precision, steps, warmup, rank, local_rank, torch, keep_field=True):
@@ -276,7 +292,8 @@ def quick_rate(args, N, precision, steps, warmup, rank, local_rank, torch, keep_
     boxes = _make_boxes(args, N, precision, args.streams, rank, local_rank)
     try:
         dt = _timed_steps(_step_fn(boxes, args.nbins, keep_field=keep_field), steps, max(warmup, len(boxes)),
-                          torch.cuda.synchronize)
+                          torch.cuda.synchronize, what="%d^3 %s" % (N, precision))
+        repeats = sum(getattr(b, "lognormal_repeats", 0) for b in boxes)
     finally:
         for b in boxes:
             b.engine.close()
@@ -284,7 +301,8 @@ def quick_rate(args, N, precision, steps, warmup, rank, local_rank, torch, keep_
     sweep = float(N) ** 3 * 2 * s
     rate = steps / dt
     return {"nsamp": N, "dtype": precision, "value": rate, "unit": "boxes/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "pipeline_frac_model_bytes": 5.0 * sweep * rate / 1e9 / HBM_PEAK_GBS}
+            "pipeline_frac_model_bytes": 5.0 * sweep * rate / 1e9 / HBM_PEAK_GBS,
+            "finite": True, "lognormal_repeats": repeats}       # (a non-finite spectrum raises: _check_finite)
 
 
 def config3_leg(N, local_rank, torch, chains=30):
@@ -312,10 +330,10 @@ def config3_leg(N, local_rank, torch, chains=30):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pend = [chain() for _ in range(chains)]
-        for p in pend:
-            p.result()
+        out = [p.result() for p in pend]
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / chains
+        _check_finite(out, "config3")
         # the remap kernel alone, un-overlapped: HIP events around every launch of its class
         eng.profile_start(["rsd"], stride=1)
         pend = [chain() for _ in range(chains)]
@@ -331,7 +349,7 @@ def config3_leg(N, local_rank, torch, chains=30):
     return {"workload": "%d^3: realise_density -> realise_velocity[2] -> redshift_space_density -> apply_transfer_fn(Wedge "
                         "slope 0.3) -> binned_power_spectrum + filtered field" % N,
             "ms_per_chain": 1e3 * dt, "value": 1.0 / dt, "unit": "chains/s", "chains": chains, "dtype": "f32",
-            "model_sweeps": 13.5, "pipeline_frac_model_bytes": 13.5 * sweep / dt / 1e9 / HBM_PEAK_GBS,
+            "model_sweeps": 13.5, "pipeline_frac_model_bytes": 13.5 * sweep / dt / 1e9 / HBM_PEAK_GBS, "finite": True,
             "rsd_roofline": {"kernel": "k_rsd_cells", "bound": "hbm", "algorithmic_bytes": rsd_bytes,
                              "avg_launch_us": 1e3 * rsd_ms / max(rsd_n, 1), "achieved": rsd_gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": rsd_gbs / HBM_PEAK_GBS if rsd_gbs else None}}
@@ -459,17 +477,16 @@ def main():
     if in_region:
         eng.profile_start(None if args.all_kernel_events else ["fft_strided"], stride=ev_stride)
     t0 = time.perf_counter()
-    acc = np.zeros(args.nbins - 1)
     pending = [step() for _ in range(args.steps)]
-    for pnd in pending:
-        kc, pk, err = pnd.result()
-        acc += np.nan_to_num(pk)
+    spectra = [pnd.result() for pnd in pending]
     if in_region:
         prof = eng.profile_stop()                    # synchronises the launch stream
         plain_launches = eng.profile_seen() if ev_stride > 1 else prof["fft_strided"][1]
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
+    _check_finite(spectra, "timed region")       # every rank: a rank that timed garbage stops the job
+    ln_repeats = sum(getattr(b, "lognormal_repeats", 0) for b in boxes)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=args._reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -498,6 +515,7 @@ def main():
         "value": world * args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "finite": True, "lognormal_repeats": ln_repeats,
         "config": {"workload": "%d^3 Gaussian box (device Philox4x32-10 noise, stand-in EH P(k), L=1000 Mpc) + "
                                "log-normal transform + binned P(k), nbins=%d" % (N, args.nbins),
                    "nsamp": N, "parallelism": "replicas x%d" % world, "streams_per_gpu": len(boxes),
@@ -591,14 +609,13 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
         fence()
         t0 = time.perf_counter()
         if wait:
-            for _ in range(nsteps):
-                box.realise_and_power(nbins=args.nbins, lognormal=True)
+            out = [box.realise_and_power(nbins=args.nbins, lognormal=True) for _ in range(nsteps)]
         else:
             tickets = [box.realise_and_power(nbins=args.nbins, lognormal=True, wait=False) for _ in range(nsteps)]
-            for tk in tickets:
-                tk.result()
+            out = [tk.result() for tk in tickets]
         fence()
         d = time.perf_counter() - t0
+        _check_finite(out, "slab %d^3" % N)
         if world > 1:
             t = torch.tensor([d], dtype=torch.float64, device=args._reduce_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -625,7 +642,7 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
             "metric": "%d^3 box realisations/sec (gen + log-normal + P(k)), one box over all GPUs" % N,
             "value": args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic", "finite": True, "lognormal_repeats": box.ln_repeats,
             "config": {"workload": "%d^3 Gaussian box + log-normal + binned P(k), slab-decomposed FFT, one all-to-all "
                                    "per transform" % N, "nsamp": N,
                        "parallelism": "slab x%d" % world,

@@ -50,6 +50,7 @@ SIGNATURES = {
                                   c_int, c_void_p]),
     "fb_sum_real": (c_int, [c_void_p, c_void_p, c_int, P_double, c_void_p]),
     "fb_sumsq_half": (c_int, [c_void_p, c_void_p, P_double, c_void_p]),
+    "fb_max_real": (c_int, [c_void_p, c_void_p, P_double, c_void_p]),
     "fb_expand_half": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_crop_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_realise_density_device": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p, c_void_p]),
@@ -108,6 +109,7 @@ SIGNATURES = {
     "fb_stream_sync": (c_int, [c_void_p]),
     "fb_stream_wait_stream": (c_int, [c_void_p, c_void_p]),
     "fb_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "fb_device_get": (c_int, [ctypes.POINTER(c_int)]),
     "fb_device_set": (c_int, [c_int]),
 }
 
@@ -168,6 +170,28 @@ def check(name, code):
 
 def call(name, *args):
     check(name, getattr(load(), name)(*args))
+
+
+class on_device(object):
+    """``with on_device(d): ...`` -- the plan-less helpers (fb_malloc, fb_stream_create, fb_stream_wait_stream) act on
+    the calling thread's current HIP device: make it `d` for the block and put the caller's back afterwards, so that
+    torch / RCCL in the same thread keep the current device they had."""
+
+    def __init__(self, device):
+        self.device, self.prev = int(device), None
+
+    def __enter__(self):
+        prev = c_int(-1)
+        call("fb_device_get", ctypes.byref(prev))
+        if prev.value != self.device:
+            call("fb_device_set", self.device)
+            self.prev = prev.value
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None and self.prev >= 0:
+            call("fb_device_set", self.prev)
+        return False
 
 
 def device_count():

@@ -66,21 +66,37 @@ class _Ready(object):
 class PendingSpectrum(object):
     """Handle on a power spectrum whose bin sums are still being computed on the device."""
 
-    def __init__(self, engine, res, nbins, kc, boxfactor, ln_voxels, keepalive):
+    def __init__(self, engine, res, nbins, kc, boxfactor, ln_voxels, keepalive, redo=None):
         self._eng, self._res, self._nb, self._kc, self._bf = engine, res, nbins, kc, boxfactor
         self._lnv, self._keep, self._out = ln_voxels, keepalive, None
         self._cnt = engine.bin_counts()
         self._raw = None                       # the device record, delivered by the engine's batched fetch
+        self._redo = redo                      # log-normal: () -> (s1, s2, esum) with the exact shift (see result)
+        self.repeated = False
         engine.register_waiter(res, self)
+
+    def _in_range(self, s1, s2, esum):
+        return hostgeom.lognormal_sums_in_range(self._cnt, s1, s2, esum)
 
     def result(self):
         if self._out is None:
             s1, s2, esum = self._eng.fetch_results(self._res, self._nb, owner=self)
-            if self._lnv:                      # transform of exp(d): rescale to exp(d)/mean - 1
+            if self._lnv:                      # transform of exp(d - shift): rescale to exp(d)/mean - 1
+                if not self._in_range(s1, s2, esum):
+                    # the shift was taken from the field's variance (hostgeom.lognormal_shift) and this realisation's
+                    # largest values lie outside what that allows for: once more, with the shift from its maximum
+                    if self._redo is None:
+                        raise FloatingPointError("log-normal P(k): the exponentials left the plan's floating-point "
+                                                 "range (sum = %r)" % (esum,))
+                    s1, s2, esum = self._redo()
+                    self.repeated = True
+                    if not self._in_range(s1, s2, esum):
+                        raise FloatingPointError("log-normal P(k): non-finite bin sums (sum of exponentials %r); "
+                                                 "is the field finite?" % (esum,))
                 mean = esum / self._lnv
                 s1, s2 = s1 / mean ** 2, s2 / mean ** 4
             self._out = (self._kc,) + _finish_bins(self._cnt, s1, s2, self._bf, _eps_of(self._eng))
-            self._res = self._keep = None
+            self._res = self._keep = self._redo = None
         return self._out
 
 
@@ -172,8 +188,9 @@ class PendingDensity(DeviceArray):
     runs that pass; ``binned_power_spectrum(delta_x=...)`` of it (or of its log-normal) instead
     fuses the pass with the power spectrum's first one, and fills in delta_x on the way."""
 
-    def __init__(self, engine, pending_half, generator=None, regenerate=None):
+    def __init__(self, engine, pending_half, generator=None, regenerate=None, sigma2=None):
         DeviceArray.__init__(self, engine, REAL, None)
+        self.sigma2 = sigma2            # variance of the distribution the field was drawn from (log-normal shift)
         self._pending = pending_half
         self.generator = generator      # (amp_key, seed, realisation): enough to regenerate delta_k
         self._regenerate = regenerate   # () -> real DeviceArray of the same realisation (counter-based generator)
@@ -236,6 +253,7 @@ class CosmoBox(object):
         self._amp_key = None
         self._bin_cache = {}
         self._delta_k = None
+        self.lognormal_repeats = 0        # fused log-normal spectra formed a second time with the exact shift
         self.set_fft_sample_spacing()
         self.engine = Engine(self.N, (self.Lx, self.Ly, self.Lz), self._axis2, self._ksc, self._kpar, self.z,
                              precision=precision, device=device, stream=stream)
@@ -379,6 +397,7 @@ class CosmoBox(object):
             half = eng.colour_noise(re, im)
             del re, im
             delta_x = eng.fft_c2r(half, destroy=True)
+            delta_x.sigma2 = self._sigma2
         else:
             # generator fused into the first inverse FFT pass (no coloured spectrum round trip); the
             # last pass is deferred so that a following P(k) can fuse it with its own first pass
@@ -393,7 +412,7 @@ class CosmoBox(object):
                 box._set_amplitude(*amp_key)
                 return box.engine.realise_fused(seed, real)
             delta_x = PendingDensity(eng, eng.realise_begin(seed, real), generator=(amp_key, seed, real),
-                                     regenerate=again)
+                                     regenerate=again, sigma2=self._sigma2)
             self.last_realisation = self._realisation
             self._realisation += 1
         if inplace:
@@ -619,10 +638,28 @@ class CosmoBox(object):
             # fused path (cubic boxes): r2c with the binning inside the last pass
             ln = isinstance(delta_x, LognormalField) and not delta_x.materialised and bins[0] > 0.
             src = delta_x.source if ln else self._as_real(delta_x)
-            # log-normal of this box's own realisation: exp(d - sigma^2/2) instead of exp(d) -- the estimate
-            # exp(d)/<exp(d)> - 1 is the same, and a single-precision plan's sums stay finite for sigma ~ 8
-            # (a non-linear P(k) sampled at 2 Mpc: exp(d) reaches 1e19, |delta_k|^4 would overflow)
-            shift = 0.5 * getattr(self, "_sigma2", 0.0) if (ln and src is getattr(self, "delta_x", None)) else 0.0
+            # log-normal: exp(d - shift) instead of exp(d) -- the estimate exp(d)/<exp(d)> - 1 is the same, and with the
+            # right shift a single-precision plan's sums stay inside the float range (a non-linear P(k) sampled at
+            # 2 Mpc gives sigma = 8, exp(d) reaches 1e19 and |delta_k|^4 would overflow; at 0.5 Mpc sigma = 21).  A field
+            # this box drew carries the variance of its distribution: the shift comes from that without a look at the
+            # data (hostgeom.lognormal_shift; a realisation whose extremes fall outside is repeated with the exact shift,
+            # PendingSpectrum.result).  Any other field is asked for its maximum first.
+            shift, redo = 0.0, None
+            if ln:
+                nvox = float(self.N) ** 3
+                sigma2 = getattr(src, "sigma2", None)
+                if sigma2 is not None:
+                    shift = hostgeom.lognormal_shift(sigma2, nvox)
+                else:
+                    shift = hostgeom.lognormal_shift_exact(eng.max_real(src), nvox)
+                nb_, bin_args = bins.size, (bins, thr, amb)
+
+                def redo(src=src):
+                    self.lognormal_repeats += 1
+                    eng.set_bins(*bin_args)
+                    exact = hostgeom.lognormal_shift_exact(eng.max_real(src), nvox)     # (materialises a pending field)
+                    res2, _ = eng.power_fused(src, pre_exp=True, exp_shift=exact)
+                    return eng.fetch_results(res2, nb_)
             if isinstance(src, PendingDensity) and not src.materialised and src._pending is not None:
                 res, real = eng.power_pending(src._pending, pre_exp=ln, exp_shift=shift, keep_field=keep_field)     # z passes fused
                 if real is not None:
@@ -631,7 +668,7 @@ class CosmoBox(object):
                     src._pending = None        # consumed; reading the field later regenerates it
             else:
                 res, _ = eng.power_fused(src, pre_exp=ln, exp_shift=shift)
-            pending = PendingSpectrum(eng, res, bins.size, kc, self.boxfactor, self.N ** 3 if ln else None, None)
+            pending = PendingSpectrum(eng, res, bins.size, kc, self.boxfactor, self.N ** 3 if ln else None, None, redo)
             return pending if not wait else pending.result()
 
         if delta_x is not None:

@@ -69,14 +69,11 @@ class Cosmology(object):
         C0 = 14.2 + 731.0 / (1.0 + 62.5 * q)
         return L0 / (L0 + C0 * q * q)
 
-    def _transfer_wiggles(self, k):
-        """EH98 eqs. 2-24 (CDM + baryons, no neutrinos); ``k`` in 1/Mpc."""
+    def _eh98_scales(self):
+        """(z_eq, k_eq [1/Mpc], z_drag, sound horizon s [Mpc], k_silk [1/Mpc]): EH98 eqs. 2-7."""
         p = self._p
         h = p['h']
-        om, ob = p['Omega_m'], p['Omega_b']
-        omh2, obh2 = om * h * h, ob * h * h
-        fb = ob / om
-        fc = 1.0 - fb
+        omh2, obh2 = p['Omega_m'] * h * h, p['Omega_b'] * h * h
         th2 = (p['T_CMB'] / 2.7) ** 2
         zeq = 2.50e4 * omh2 / th2 ** 2
         keq = 7.46e-2 * omh2 / th2
@@ -87,6 +84,19 @@ class Cosmology(object):
         Rd = 31.5 * obh2 / th2 ** 2 * (1e3 / zd)
         s = 2.0 / (3.0 * keq) * np.sqrt(6.0 / Req) * np.log((np.sqrt(1.0 + Rd) + np.sqrt(Rd + Req)) / (1.0 + np.sqrt(Req)))
         ksilk = 1.6 * obh2 ** 0.52 * omh2 ** 0.73 * (1.0 + (10.4 * omh2) ** -0.95)
+        return zeq, keq, zd, s, ksilk
+
+    def _transfer_wiggles(self, k):
+        """EH98 eqs. 2-24 (CDM + baryons, no neutrinos); ``k`` in 1/Mpc."""
+        p = self._p
+        h = p['h']
+        om, ob = p['Omega_m'], p['Omega_b']
+        omh2, obh2 = om * h * h, ob * h * h
+        fb = ob / om
+        fc = 1.0 - fb
+        th2 = (p['T_CMB'] / 2.7) ** 2
+        zeq, keq, zd, s, ksilk = self._eh98_scales()
+        Rd = 31.5 * obh2 / th2 ** 2 * (1e3 / zd)
         q = k / (13.41 * keq)
         a1 = (46.9 * omh2) ** 0.670 * (1.0 + (32.1 * omh2) ** -0.532)
         a2 = (12.0 * omh2) ** 0.424 * (1.0 + (45.0 * omh2) ** -0.582)

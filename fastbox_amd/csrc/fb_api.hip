@@ -23,11 +23,27 @@ int fb_hip_check(hipError_t e, const char* what) {
 // HIP runtime may have left in this thread, so that the launch checks below report this call's errors only)
 #define FB_REQUIRE(cond, msg) do { (void)hipGetLastError(); if (!(cond)) { fb_set_error(msg); return FB_ERR_INVALID; } } while (0)
 #define FB_DISPATCH(p, call32, call64) ((p)->prec == 4 ? (call32) : (call64))
-// A plan belongs to one device.  Every entry point that takes a plan makes that device current first (allocations,
-// NULL-stream launches and the plan's own auxiliary stream / events all follow the current device), so plans on
-// different GPUs can be used from one thread in any order.
-#define FB_USE_DEVICE(p) do { int _dev = -1; if (hipGetDevice(&_dev) != hipSuccess || _dev != (p)->device) \
-                                  FB_HIP(hipSetDevice((p)->device)); } while (0)
+// A plan belongs to one device.  Every entry point that takes a plan makes that device current for the duration of the
+// call (allocations, NULL-stream launches and the plan's own auxiliary stream / events all follow the current device)
+// and puts the caller's device back when it returns -- other users of the HIP runtime in this thread (torch, RCCL)
+// keep the current device they had -- so plans on different GPUs can be used from one thread in any order.
+namespace {
+struct FbDeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    int enter(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+        if (prev != dev) {
+            const int r = fb_hip_check(hipSetDevice(dev), "hipSetDevice");
+            if (r) return r;
+            changed = prev >= 0;
+        }
+        return FB_OK;
+    }
+    ~FbDeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+};
+}  // namespace
+#define FB_USE_DEVICE(p) FbDeviceGuard _fb_devguard; do { const int _r = _fb_devguard.enter((p)->device); if (_r) return _r; } while (0)
 
 namespace {
 template <typename T> int upload(T** dst, const T* src, size_t n) {
@@ -56,6 +72,12 @@ const char* fb_last_error(void) { return g_last_error.c_str(); }
 int fb_device_count(int* count) {
     FB_REQUIRE(count, "null pointer");
     FB_HIP(hipGetDeviceCount(count));
+    return FB_OK;
+}
+
+int fb_device_get(int* device) {
+    FB_REQUIRE(device, "null pointer");
+    FB_HIP(hipGetDevice(device));
     return FB_OK;
 }
 
@@ -294,6 +316,12 @@ int fb_sum_real(fb_plan* p, const void* x, int squared, double* out, void* strea
     FB_USE_DEVICE(p);
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_sum_real_f32(p, x, squared, out, s), fbi_sum_real_f64(p, x, squared, out, s));
+}
+int fb_max_real(fb_plan* p, const void* x, double* out, void* stream) {
+    FB_REQUIRE(p && x && out, "null pointer");
+    FB_USE_DEVICE(p);
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_max_real_f32(p, x, out, s), fbi_max_real_f64(p, x, out, s));
 }
 int fb_sumsq_half(fb_plan* p, const void* h, double* out, void* stream) {
     FB_REQUIRE(p && h && out, "null pointer");

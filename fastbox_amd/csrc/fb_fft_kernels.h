@@ -764,7 +764,8 @@ __device__ __forceinline__ float fb_exp(float x) {
     float e = __builtin_fmaf(x, 1.44269502162933349609375f, -t);           // exact rounding error of the product
     e = __builtin_fmaf(x, 1.925963033500011e-8f, e);                       // log2 e - float(log2 e)
     const float r = __builtin_amdgcn_exp2f(t);
-    return __builtin_fmaf(r, 0.693147182464599609375f * e, r);
+    // (overflow: r = inf and, where the correction is exactly 0, inf * 0 + inf would be NaN; libm's expf gives inf)
+    return r > 3.4028234663852886e38f ? r : __builtin_fmaf(r, 0.693147182464599609375f * e, r);
 #endif
 }
 enum { ZMODE_C2C = 0, ZMODE_R2C = 1, ZMODE_C2R = 2, ZMODE_C2R2C = 3 };

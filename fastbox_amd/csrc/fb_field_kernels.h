@@ -267,22 +267,29 @@ __device__ __forceinline__ void wave_flush(int b, float s1, float s2, bool have,
     }
 }
 
-// block partial sums of f(x); OP 0: x, 1: x^2, 2: exp(x) (also written to out)
+// block partial sums of f(x); OP 0: x, 1: x^2, 2: exp(x - shift) (also written to out), 3: block maxima of x instead of sums
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void k_reduce_real(const T* __restrict__ in, T* __restrict__ out, long long n,
-                                                      double* __restrict__ partial) {
+                                                      double* __restrict__ partial, T shift = 0) {
     __shared__ double ws[4];
-    double s = 0.0;
+    double s = OP == 3 ? -1.7976931348623157e308 : 0.0;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
         T x = in[q];
         if (OP == 1) x = x * x;
-        if (OP == 2) { x = exp(x); out[q] = x; }
-        s += (double)x;
+        if (OP == 2) { x = exp(x - shift); out[q] = x; }
+        if (OP == 3) s = (double)x > s ? (double)x : s;        // (a NaN never wins: the maximum of the finite values)
+        else s += (double)x;
     }
-    s = wave_sum(s);
+    if (OP == 3) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(s, o, 64); s = t > s ? t : s; }
+    } else s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    if (threadIdx.x == 0) {
+        if (OP == 3) { const double a = ws[0] > ws[1] ? ws[0] : ws[1], b = ws[2] > ws[3] ? ws[2] : ws[3]; partial[blockIdx.x] = a > b ? a : b; }
+        else partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    }
 }
 // sum over the FULL grid of |delta_k|^2 from a half spectrum (box.py:946)
 template <typename T>

@@ -160,6 +160,7 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_rsd_##sfx(fb_plan* p, const void* d, const void* vz, const void* noise, void* out, double Hz, \
                       double sigma, uint64_t seed, int nearest, hipStream_t s); \
     int fbi_sum_real_##sfx(fb_plan* p, const void* x, int squared, double* out, hipStream_t s); \
+    int fbi_max_real_##sfx(fb_plan* p, const void* x, double* out, hipStream_t s); \
     int fbi_sumsq_half_##sfx(fb_plan* p, const void* h, double* out, hipStream_t s); \
     int fbi_expand_half_##sfx(fb_plan* p, const void* h, void* f, hipStream_t s); \
     int fbi_crop_full_##sfx(fb_plan* p, const void* f, void* h, hipStream_t s); \

@@ -175,13 +175,18 @@ def new_stream(device=None, priority=None):
     boxes on different streams overlap on the GPU (compute-bound passes of one with memory-bound
     passes of the other).  ``device``: the GPU the stream is for (default: the current one);
     ``priority``: None (default), or < 0 / 0 / > 0 for the device's highest / middle / lowest stream priority."""
-    if device is not None:
-        _lib.call("fb_device_set", int(device))
     s = ctypes.c_void_p()
-    if priority is None:
-        _lib.call("fb_stream_create", ctypes.byref(s))
+
+    def make():
+        if priority is None:
+            _lib.call("fb_stream_create", ctypes.byref(s))
+        else:
+            _lib.call("fb_stream_create_priority", ctypes.byref(s), int(priority))
+    if device is None:
+        make()
     else:
-        _lib.call("fb_stream_create_priority", ctypes.byref(s), int(priority))
+        with _lib.on_device(device):
+            make()
     return s.value
 
 
@@ -247,20 +252,20 @@ class Engine(object):
         if free:
             return _Buffer(free.pop(), nbytes, self._pool)
         p = ctypes.c_void_p()
-        _lib.call("fb_device_set", self.device)            # fb_malloc serves the current device
-        try:
-            _lib.call("fb_malloc", ctypes.byref(p), nbytes)
-        except _lib.FastBoxError as e:
-            if e.code != -4:                               # FB_ERR_NOMEM
-                raise
-            # out of device memory: drop what nobody uses any more -- engines of boxes that are gone (reference
-            # cycles keep them until a collection) and every live engine's cache of idle buffers -- and try once more
-            import gc
-            gc.collect()
-            self.sync()
-            for eng in list(_ENGINES):
-                eng.release_idle_buffers()
-            _lib.call("fb_malloc", ctypes.byref(p), nbytes)
+        with _lib.on_device(self.device):                  # fb_malloc serves the current device
+            try:
+                _lib.call("fb_malloc", ctypes.byref(p), nbytes)
+            except _lib.FastBoxError as e:
+                if e.code != -4:                           # FB_ERR_NOMEM
+                    raise
+                # out of device memory: drop what nobody uses any more -- engines of boxes that are gone (reference
+                # cycles keep them until a collection) and every live engine's cache of idle buffers -- and try once more
+                import gc
+                gc.collect()
+                self.sync()
+                for eng in list(_ENGINES):
+                    eng.release_idle_buffers()
+                _lib.call("fb_malloc", ctypes.byref(p), nbytes)
         return _Buffer(p.value, nbytes, self._pool)
 
     def release_idle_buffers(self):
@@ -485,8 +490,8 @@ class Engine(object):
     def wait_for(self, other):
         """What is queued on this engine's stream from now on starts after everything queued on `other`'s stream so
         far has finished (no host wait).  Two boxes sharing a GPU use it to keep their generator passes apart."""
-        _lib.call("fb_device_set", self.device)
-        _lib.call("fb_stream_wait_stream", self.stream, other.stream)
+        with _lib.on_device(self.device):
+            _lib.call("fb_stream_wait_stream", self.stream, other.stream)
 
     def realise_begin(self, seed, realisation):
         """Generator + x pass; returns the pending half spectrum (y and z passes still to do)."""
@@ -551,8 +556,8 @@ class Engine(object):
         still unfetched by then is brought to the host first."""
         if self._res_dev is None:
             p = ctypes.c_void_p()
-            _lib.call("fb_device_set", self.device)
-            _lib.call("fb_malloc", ctypes.byref(p), self.RES_SLOTS * self.RES_STRIDE * 8)
+            with _lib.on_device(self.device):
+                _lib.call("fb_malloc", ctypes.byref(p), self.RES_SLOTS * self.RES_STRIDE * 8)
             self._res_dev = p.value
             self._res_host = np.zeros((self.RES_SLOTS, self.RES_STRIDE))
         if self._res_next - self._res_fetched >= self.RES_SLOTS:
@@ -632,6 +637,12 @@ class Engine(object):
     def sum_real(self, real, squared=False):
         v = ctypes.c_double()
         _lib.call("fb_sum_real", self._plan, real.ptr, 1 if squared else 0, ctypes.byref(v), self.stream)
+        return v.value
+
+    def max_real(self, real):
+        """Largest finite value of a real field (waits for the stream)."""
+        v = ctypes.c_double()
+        _lib.call("fb_max_real", self._plan, real.ptr, ctypes.byref(v), self.stream)
         return v.value
 
     def sumsq_half(self, half):

@@ -94,6 +94,10 @@ class HipSlabOps(object):
     def bin_counts(self):
         return self.engine.bin_counts()
 
+    def max_real(self, real):
+        """Largest value of this rank's real slab (a device reduction of torch's; the caller all-reduces it)."""
+        return float(real.max().item())
+
     # transforms
     def x_generate(self, kslab, seed, realisation):
         self._call("fb_slab_x_generate", kslab.data_ptr(), self.P, self.part, seed & (2 ** 64 - 1),
@@ -166,10 +170,14 @@ class SlabBox(object):
         self.ops = ops_factory(self.g, world, rank)
         amp = hostgeom.shell_amplitude(N, self.g["L"][0], self.boxfactor, pk_fn)
         self.ops.set_amplitude(amp)
-        # fused log-normal transforms form exp(d - sigma^2/2): same estimate, sums in range on single-precision plans
+        # fused log-normal transforms form exp(d - shift): same estimate, and with the shift taken from the variance of
+        # the fields this box draws the sums stay in range on single-precision plans (hostgeom.lognormal_shift; a
+        # realisation whose extremes fall outside is repeated with the shift from its own maximum, _redo_lognormal)
         self._sigma2 = hostgeom.field_variance_cubic(N, amp)
+        self._ln_shift = hostgeom.lognormal_shift(self._sigma2, float(N) ** 3)
+        self.ln_repeats = 0
         if hasattr(self.ops, "set_exp_shift"):
-            self.ops.set_exp_shift(0.5 * self._sigma2)
+            self.ops.set_exp_shift(self._ln_shift)
         self._kslab = self.ops.new_kslab()
         self._xbuf = self.ops.new_kslab()          # same byte count as [P][N/P][N/P][pitch]
         self._half = self.ops.new_half_local()
@@ -181,6 +189,7 @@ class SlabBox(object):
         self._real_mc = None
         self._ring, self._ring_next = None, 0
         self._inflight, self._retired = [], []     # _Ticket objects, oldest first
+        self._submitted = 0                        # tickets handed out so far: ticket i owns buffer pair i % 3
 
     def _fused(self, call):
         """Run the exchange-buffer-addressing form of a y pass if the backend has it and the rank count allows it
@@ -240,6 +249,7 @@ class SlabBox(object):
 
     def realise_density(self):
         """This rank's x-slab of delta_x (kept in ``self.delta_x``)."""
+        self._drain()          # tickets in flight read / write the buffers this call is about to use
         send = self._gen_local()
         return self._gen_finish(self._exchange(send, self._xbuf))
 
@@ -280,7 +290,10 @@ class SlabBox(object):
 
         ``wait=False``: returns a ticket at once; its ``result()`` gives the triple.  With several ranks up to three
         realisations are in flight and their all-to-alls overlap the passes of the others (module docstring);
-        ``flush()`` issues whatever is still outstanding, ``result()`` does so implicitly."""
+        ``flush()`` issues whatever is still outstanding, ``result()`` does so implicitly.  In this mode
+        ``self.delta_x`` is ONE buffer shared by all tickets: it holds the slab of whichever realisation went through
+        its z pass last, and the next one overwrites it (copy it after ``flush()`` to keep a field).  Any other
+        method of the box first issues what is in flight (``_drain``), so calls may be interleaved freely."""
         if not wait and self.world > 1:
             return self._submit(nbins, kbins, lognormal)
         self._drain()
@@ -299,9 +312,11 @@ class SlabBox(object):
             send = self._pk_local(real, lognormal, nb)
         other = self._kslab if send is self._xbuf else self._xbuf
         res = self._pk_finish(self._exchange(send, other), nb)
+        idx = self._realisation - 1
+        redo = lambda: self._redo_lognormal(None, nbins, kbins, realisation=idx)
         if not wait:
-            return _Deferred(self, res, kc, nb, lognormal)
-        return self._finish_power(res, kc, nb, lognormal)
+            return _Deferred(self, res, kc, nb, lognormal, redo)
+        return self._finish_power(res, kc, nb, lognormal, redo)
 
     # -- pipelined Monte-Carlo steps ----------------------------------------------------------
     RING = 64                                      # result records kept on the device before they must be fetched
@@ -377,8 +392,11 @@ class SlabBox(object):
         if self._ring_next and self._ring_next % self.RING == 0:
             self._drain()                                  # the ring is about to wrap: fetch what is pending first
             self._fetch_retired()
-        tk = _Ticket(self, kc, nb, lognormal, self._pairs[self._realisation % 3],
-                     self._ring[self._ring_next % self.RING])
+        # (the pair follows the submission count, not the realisation index: a caller may set `_realisation` to any
+        # value -- a resumed Monte-Carlo run does -- and two tickets in flight must never share a pair)
+        tk = _Ticket(self, kc, nb, lognormal, self._pairs[self._submitted % 3],
+                     self._ring[self._ring_next % self.RING], self._realisation, (nbins, kbins))
+        self._submitted += 1
         self._ring_next += 1
         # compute stream: GEN(i), turn(i-1), BIN(i-2); the collectives follow their producers on the RCCL stream
         self.ops.x_generate(tk.pair[0], self.seed, self._realisation)
@@ -398,18 +416,31 @@ class SlabBox(object):
         """Issue the remaining stages of every realisation submitted with ``wait=False``."""
         self._drain()
 
-    def _finish_power(self, res, kc, nb, lognormal):
+    def _finish_power(self, res, kc, nb, lognormal, redo=None):
         self._all_reduce(res)                                     # 2*nbins+1 doubles
-        h = res.detach().cpu().numpy()
-        s1, s2, esum = h[0:2 * nb:2].copy(), h[1:2 * nb:2].copy(), h[2 * nb]
+        return self._finish_host(res.detach().cpu().numpy(), kc, nb, lognormal, redo)
+
+    def _finish_host(self, h, kc, nb, lognormal, redo=None):
+        """(kc, pk, stddev) from the all-reduced record; a log-normal record whose exponentials left the plan's
+        floating-point range (hostgeom.lognormal_sums_in_range) is formed again by `redo` with the exact shift."""
+        cnt = self.ops.bin_counts()
+        for attempt in (0, 1):
+            s1, s2, esum = h[0:2 * nb:2].copy(), h[1:2 * nb:2].copy(), h[2 * nb]
+            if not lognormal or hostgeom.lognormal_sums_in_range(cnt, s1, s2, esum):
+                break
+            if attempt or redo is None:
+                raise FloatingPointError("log-normal P(k): the exponentials left the plan's floating-point range "
+                                         "(sum = %r)" % (esum,))
+            h = redo()
         if lognormal:
             mean = esum / float(self.N) ** 3
             s1, s2 = s1 / mean ** 2, s2 / mean ** 4
-        return (kc,) + hostgeom.finish_bins(self.ops.bin_counts(), s1, s2, self.boxfactor, self._eps)
+        return (kc,) + hostgeom.finish_bins(cnt, s1, s2, self.boxfactor, self._eps)
 
     def binned_power_spectrum(self, delta_x=None, nbins=20, kbins=None, lognormal=False):
         """P(k) of the distributed field (of its log-normal transform if ``lognormal``); every rank
         returns the full (kc, pk, stddev) triple."""
+        self._drain()          # tickets in flight read / write the buffers this call is about to use
         real = self.delta_x if delta_x is None else delta_x
         bins, kc = self._pk_setup(nbins, kbins)
         nb = bins.size
@@ -417,14 +448,44 @@ class SlabBox(object):
             raise ValueError("the fused log-normal P(k) needs kbins[0] > 0")
         send = self._pk_local(real, lognormal, nb)
         res = self._pk_finish(self._exchange(send, self._kslab), nb)
-        return self._finish_power(res, kc, nb, lognormal)
+        return self._finish_power(res, kc, nb, lognormal, redo=lambda: self._redo_lognormal(real, nbins, kbins))
+
+    def _redo_lognormal(self, real, nbins, kbins, realisation=None):
+        """Bin sums of the log-normal transform of `real` (or of realisation number `realisation`, drawn again) with
+        the shift taken from the field's own maximum: the repeat of a step whose exponentials left the plan's
+        floating-point range.  Collective (the sums that decide it are all-reduced, so every rank gets here)."""
+        self._drain()
+        if realisation is not None:
+            keep = self._realisation
+            self._realisation = realisation
+            real = self.realise_density()
+            self._realisation = keep
+        import torch
+        m = torch.tensor([self.ops.max_real(real)], dtype=torch.float64)
+        if self.world > 1:
+            if self._dist.get_backend(self.group) != "gloo":
+                m = m.to(real.device)
+            self._dist.all_reduce(m, op=self._dist.ReduceOp.MAX, group=self.group)
+        self.ops.set_exp_shift(hostgeom.lognormal_shift_exact(float(m.item()), float(self.N) ** 3))
+        try:
+            bins, kc = self._pk_setup(nbins, kbins)
+            nb = bins.size
+            send = self._pk_local(real, True, nb)
+            res = self._pk_finish(self._exchange(send, self._kslab), nb)
+            self._all_reduce(res)
+            h = res.detach().cpu().numpy()
+        finally:
+            self.ops.set_exp_shift(self._ln_shift)
+        self.ln_repeats += 1
+        return h
 
 
 class _Ticket(object):
     """One pipelined realisation + P(k) of a SlabBox (see SlabBox._submit)."""
 
-    def __init__(self, box, kc, nb, lognormal, pair, res):
+    def __init__(self, box, kc, nb, lognormal, pair, res, realisation, bin_args):
         self.box, self.kc, self.nb, self.lognormal, self.pair, self.res = box, kc, nb, lognormal, pair, res
+        self.realisation, self.bin_args = realisation, bin_args
         self.state, self.w1, self.w2, self.w3 = "gen", None, None, None
         self._host = None
 
@@ -440,22 +501,19 @@ class _Ticket(object):
         return self._host
 
     def result(self):
-        h, nb, box = self.fetch(), self.nb, self.box
-        s1, s2, esum = h[0:2 * nb:2].copy(), h[1:2 * nb:2].copy(), h[2 * nb]
-        if self.lognormal:
-            mean = esum / float(box.N) ** 3
-            s1, s2 = s1 / mean ** 2, s2 / mean ** 4
-        return (self.kc,) + hostgeom.finish_bins(box.ops.bin_counts(), s1, s2, box.boxfactor, box._eps)
+        box = self.box
+        redo = lambda: box._redo_lognormal(None, self.bin_args[0], self.bin_args[1], realisation=self.realisation)
+        return box._finish_host(self.fetch(), self.kc, self.nb, self.lognormal, redo)
 
 
 class _Deferred(object):
     """wait=False on a single rank: the step has been queued, the bin sums are fetched on ``result()``."""
 
-    def __init__(self, box, res, kc, nb, lognormal):
-        self.box, self.res, self.kc, self.nb, self.lognormal = box, res, kc, nb, lognormal
+    def __init__(self, box, res, kc, nb, lognormal, redo=None):
+        self.box, self.res, self.kc, self.nb, self.lognormal, self.redo = box, res, kc, nb, lognormal, redo
 
     def result(self):
-        return self.box._finish_power(self.res, self.kc, self.nb, self.lognormal)
+        return self.box._finish_power(self.res, self.kc, self.nb, self.lognormal, self.redo)
 
 
 def run_virtual(boxes, fn_local, fn_finish):

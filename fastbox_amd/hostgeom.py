@@ -76,6 +76,56 @@ def field_variance_sym(N, amp_sym):
     return float(np.einsum("i,j,k,ijk->", w, w, w, a * a) / float(N) ** 6)
 
 
+LN_SUM_MAX = 21.0        # ln of the largest sum of shifted exponentials a single-precision plan can carry: the k = 0
+                         # mode of the transform IS that sum and its |.|^4 must stay below 2^128 (e^88.7)
+
+
+def lognormal_shift(sigma2, nvox):
+    """Shift c of the fused log-normal transform, which forms exp(delta - c): the estimate exp(d)/<exp(d)> - 1
+    (box.py:457-460) and its P(k) do not depend on c, but on a single-precision plan the sums only stay in range
+    for the right c.  Chosen from where S = sum exp(delta) of nvox Gaussian values of variance sigma2 will lie:
+
+      sigma <= a = sqrt(2 ln nvox):  the sum is the sample mean's,  ln S = ln nvox + sigma^2/2  ->  S e^-c = e^7
+      sigma >  a                  :  the sum is its few largest terms, ln S ~ max delta, a Gumbel variable of
+                                     location mu = sigma (a - (ln ln nvox + ln 4 pi) / (2 a)) and scale sigma / a
+                                     ->  the largest term lands at e^-6 (27 e-folds of head room above, since the
+                                     upper tail of the maximum is the wide one; 14 below before anything that
+                                     matters flushes to zero)
+
+    (sigma^2/2, round 2's choice, is the first line without the ln nvox; past sigma ~ 13 it puts EVERY term below
+    the single-precision range: 2048^3 at 2 Mpc/voxel has sigma = 21 and max delta - sigma^2/2 = -94.)
+    A realisation that falls outside the range anyway is detected by its non-finite sums and repeated with the
+    exact shift, `lognormal_shift_exact`."""
+    sigma2 = max(float(sigma2), 0.0)
+    if sigma2 == 0.0 or nvox < 2:
+        return 0.0
+    sigma, ln_n = np.sqrt(sigma2), np.log(float(nvox))
+    a = np.sqrt(2. * ln_n)
+    if sigma <= a:
+        return float(ln_n + 0.5 * sigma2 - 7.0)
+    mu = sigma * (a - (np.log(ln_n) + np.log(4. * np.pi)) / (2. * a))
+    return float(mu + 6.0)
+
+
+def lognormal_shift_exact(dmax, nvox):
+    """The shift for a field whose maximum is known: every term is <= e^-m with m = max(0, ln nvox - LN_SUM_MAX),
+    so the sum lies in [e^-m, e^LN_SUM_MAX] whatever the field looks like."""
+    return float(dmax) + max(0.0, np.log(float(nvox)) - LN_SUM_MAX)
+
+
+def lognormal_sums_in_range(cnt, s1, s2, esum):
+    """Did the shifted exponentials of a fused log-normal P(k) stay inside the plan's floating-point range?
+    Overflow shows as non-finite sums (or a sum of exponentials that is not a positive number); underflow as a
+    non-empty bin whose sum of squares has lost terms, i.e. lies below (sum)^2 / n, which no set of real numbers
+    does.  Bin 0 is the reference's discarded one (box.py:761-764) and is not looked at."""
+    c = np.asarray(cnt)[1:]
+    ok = c > 0
+    a, b = np.asarray(s1)[1:][ok], np.asarray(s2)[1:][ok]
+    if not (np.isfinite(esum) and esum > 0. and np.all(np.isfinite(a)) and np.all(np.isfinite(b))):
+        return False
+    return bool(np.all(a > 0.) and np.all(b * c[ok] >= a * a * (1. - 1e-3)))
+
+
 def bin_edges(g, nbins=20, kbins=None):
     """Edges and the centres of bins 1..nbins-1 (box.py:745-751)."""
     if kbins is not None:
@@ -106,16 +156,18 @@ def shell_thresholds(N, Lside, bins):
 
 
 def finish_bins(cnt, s1, s2, boxfactor, eps=0.):
-    """(mean, std/sqrt(n)) per bin from (count, sum |dk|^2, sum |dk|^4), bin 0 dropped
-    (box.py:761-768); exactly 0 spread for single-valued bins (a mirrored pair of modes), as np.std gives, NaN for
-    empty ones.  ``eps``: rounding unit of the |dk|^2 values the sums were formed from (2^-23 for a single-precision
-    plan).  A variance below 4 eps mean^2 is rounding of the squares, not spread -- the form sum p^2 - (sum p)^2/n of
-    a single-valued bin leaves +-eps p^2, whose square root would read as a spread of 2e-4 -- and is reported as 0."""
+    """(mean, std/sqrt(n)) per bin from (count, sum |dk|^2, sum |dk|^4), bin 0 dropped (box.py:761-768); NaN for empty
+    bins.  ``eps``: rounding unit of the |dk|^2 values the sums were formed from (2^-23 for a single-precision plan).
+    A bin that holds one mode and its mirror image (count 2: the same |dk|^2 twice for a real field) has exactly 0
+    spread in the reference's np.std; the form sum p^2 - (sum p)^2 / n leaves +-eps p^2 of rounding there instead,
+    whose square root would read as a spread of 2e-4 -- so for such a pair, and only there, a variance below
+    4 eps mean^2 is reported as 0.  Every other bin gets the variance its sums give (a spread below ~sqrt(eps) of the
+    mean is beyond what sums of single-precision squares resolve; the fp64 plan resolves 1e-8)."""
     with np.errstate(all="ignore"):
         vals = s1 / (cnt * boxfactor)
         var = (s2 - s1 * s1 / cnt) / cnt
         if eps:
-            var = np.where(var <= 4. * eps * (s1 / cnt) ** 2, 0., var)
+            var = np.where((cnt == 2) & (var <= 4. * eps * (s1 / cnt) ** 2), 0., var)
         stddev = np.sqrt(np.maximum(var, 0.)) / boxfactor / np.sqrt(cnt)
     return np.array(vals[1:]), np.array(stddev[1:])
 

@@ -22,8 +22,9 @@ import numpy as np
 class BandPowerAccumulator(object):
     """Welford mean / co-moment sums of band-power vectors, fp64 on the host."""
 
-    def __init__(self):
+    def __init__(self, size=None):
         self.n, self.mean, self.m2 = 0, None, None
+        self.size = size            # length of the vectors to come (known to `run` before the first one arrives)
 
     def add(self, x):
         x = np.nan_to_num(np.asarray(x, dtype=np.float64))
@@ -45,6 +46,8 @@ class BandPowerAccumulator(object):
     def from_raw_sums(cls, n, s1, s2):
         a = cls()
         a.n = int(n)
+        if a.n == 0:
+            return a
         a.mean = s1 / n
         a.m2 = s2 - n * np.outer(a.mean, a.mean)
         return a
@@ -66,6 +69,21 @@ def _load(path):
     return json.loads(str(g["meta"])), acc, (g["kc"].copy() if g["kc"].size else None)
 
 
+def _physics_id(box):
+    """What else decides the numbers of a run: the input spectrum (through the amplitudes the box would draw with, at
+    its own redshift and its default non-linear P(k)), the plan's precision.  A checkpoint written with another
+    cosmology, redshift or precision must not be continued."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(repr((getattr(box, "redshift", None), getattr(getattr(box, "engine", None), "precision", None))).encode())
+    power = getattr(box, "_power", None)
+    if power is not None:
+        k = 2. * np.pi * np.sqrt(np.arange(1, 3 * (int(box.N) // 2) ** 2 + 1, 97, dtype=np.float64)) / float(box.Lx)
+        with np.errstate(all="ignore"):
+            h.update(np.nan_to_num(np.asarray(power(k, getattr(box, "scale_factor", 1.0), False), dtype=np.float64)).tobytes())
+    return h.hexdigest()[:16]
+
+
 def run(box, realisations, nbins=20, lognormal=False, batch=50, rank=0, world=1, checkpoint=None,
         checkpoint_every=1, on_batch=None, keep_fields=False):
     """P(k) of realisations r = rank, rank + world, ... < `realisations` of ``box`` (a CosmoBox with rng='device').
@@ -76,13 +94,14 @@ def run(box, realisations, nbins=20, lognormal=False, batch=50, rank=0, world=1,
     if getattr(box, "rng", "device") != "device":
         raise ValueError("the Monte-Carlo driver needs rng='device' (realisations addressed by index)")
     ident = dict(seed=int(box.seed), nsamp=int(box.N), nbins=int(nbins), lognormal=bool(lognormal), rank=int(rank),
-                 world=int(world), box=[float(box.Lx), float(box.Ly), float(box.Lz)])
-    acc, kc, done = BandPowerAccumulator(), None, 0
+                 world=int(world), box=[float(box.Lx), float(box.Ly), float(box.Lz)], physics=_physics_id(box))
+    acc, kc, done = BandPowerAccumulator(int(nbins) - 1), None, 0
     if checkpoint and os.path.exists(checkpoint):
         meta, acc0, kc0 = _load(checkpoint)
         if {k: meta.get(k) for k in ident} != ident:
             raise ValueError("checkpoint %s belongs to another run: %s" % (checkpoint, meta))
         acc, kc, done = acc0, kc0, int(meta["done"])
+        acc.size = int(nbins) - 1
     mine = [r for r in range(realisations) if r % world == rank]
     # the covariance needs the spectra only: the fused z pass does not write delta_x (it can be drawn again by index)
     spectra_only = {} if keep_fields else {"keep_field": False}
@@ -107,13 +126,26 @@ def run(box, realisations, nbins=20, lognormal=False, batch=50, rank=0, world=1,
     return acc, kc, time.perf_counter() - t0
 
 
-def combine(acc, dist=None, device=None):
-    """All-reduce the raw sums over the ranks of torch.distributed (every rank gets the combined accumulator)."""
+def combine(acc, dist=None, device=None, size=None):
+    """All-reduce the raw sums over the ranks of torch.distributed (every rank gets the combined accumulator).
+    A rank that processed no realisation (more ranks than realisations) enters the collective with zeros of the full
+    length, which it takes from the accumulator `run` returned (``acc.size``) or from ``size`` (= nbins - 1)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return acc
     import torch
-    n, s1, s2 = acc.raw_sums() if acc.n else (0, 0, 0)
-    size = acc.mean.size
+    if acc.mean is not None:
+        if size is not None and int(size) != acc.mean.size:
+            raise ValueError("size=%d but this rank's band-power vectors have %d entries" % (size, acc.mean.size))
+        size = acc.mean.size
+    if size is None:
+        size = getattr(acc, "size", None)
+    if size is None:
+        raise ValueError("combine(): this rank has no realisations; pass size=nbins - 1")
+    size = int(size)
+    if acc.n:
+        n, s1, s2 = acc.raw_sums()
+    else:
+        n, s1, s2 = 0, np.zeros(size), np.zeros((size, size))
     t = torch.tensor(np.concatenate([[n], np.ravel(s1), np.ravel(s2)]), dtype=torch.float64)
     if device is not None:
         t = t.to(device)

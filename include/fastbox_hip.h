@@ -161,8 +161,12 @@ int fb_velocity_k(fb_plan* plan, const void* dk, void* out, int layout, int comp
 int fb_potential_k(fb_plan* plan, const void* dk, void* out, int layout, void* stream);
 
 /* ---- real-space operators ---------------------------------------------------------------------- */
-/* out = exp(in)/mean(exp(in)) - 1 (box.py:457-460); *mean_out receives mean(exp(in)). Synchronises. */
+/* out = exp(in)/mean(exp(in)) - 1 (box.py:457-460), formed as exp(in - max in)/mean(exp(in - max in)) - 1 so that
+ * no intermediate leaves the plan's floating-point range; *mean_out receives mean(exp(in)). Synchronises. */
 int fb_lognormal(fb_plan* plan, const void* real_in, void* real_out, double* mean_out, void* stream);
+/* largest finite value of a real field (the exact shift of a fused log-normal transform, fb_set_exp_shift).
+ * Synchronises. */
+int fb_max_real(fb_plan* plan, const void* real, double* out, void* stream);
 /* redshift_space_density (box.py:405-437). noise: T[N][N][N] standard normals in LOS order
  * (parity) or NULL -> Philox stream 1 of `seed` when sigma_nl > 0.  method: what box.py:433-437 hands to
  * scipy's griddata -- 'linear' (the default; points outside the shifted samples get the end-point average)
@@ -303,8 +307,10 @@ int fb_set_tuning(fb_plan* plan, int stagger_plain, int stagger_gen, int stagger
 int fb_set_plane_batching(fb_plan* plan, int planes, int streams);
 /* Fused log-normal transforms (pre_exp of fb_fft_r2c / fb_power_spectrum_device / _pending) form exp(x - shift).  The
  * estimate exp(d)/mean(exp(d)) - 1 does not depend on the shift (results[2 nbins] is the sum of the SHIFTED exponentials,
- * which is what the caller normalises with); shift = sigma^2/2 of a Gaussian field keeps a single-precision plan's
- * |delta_k|^2 and |delta_k|^4 sums finite when the field's variance is large (sigma ~ 8: exp(d) reaches 1e19). */
+ * which is what the caller normalises with); the right shift keeps a single-precision plan's sum of exponentials (the
+ * k = 0 mode), its |delta_k|^2 and |delta_k|^4 sums inside the float range whatever the field's variance: about
+ * ln(sum exp(d)) - 7, see fastbox_amd/hostgeom.py lognormal_shift (from the field's variance) and lognormal_shift_exact
+ * (from fb_max_real). */
 int fb_set_exp_shift(fb_plan* plan, double shift);
 /* tuning aid: a single strided FFT pass over a half spectrum (axis 0 = x, 1 = y;
  * mode 0 plain in place, 1 fused generator, 2 fused binning without store) */
@@ -326,9 +332,12 @@ int fb_stream_sync(void* stream);
  * (both streams on the current device); the host does not wait */
 int fb_stream_wait_stream(void* waiter, void* signaller);
 int fb_device_count(int* count);
-/* Make `device` the calling thread's current HIP device.  Every entry point that takes a plan does this for the plan's
- * device itself; bindings call it before the plan-less helpers above (fb_malloc, fb_stream_create) when they serve a
- * box on a device other than the current one. */
+/* The calling thread's current HIP device.  Every entry point that takes a plan makes the plan's device current for the
+ * duration of the call and restores the caller's before it returns, so the library never moves the current device under
+ * other users of the runtime (torch, RCCL).  The plan-less helpers above (fb_malloc, fb_stream_create,
+ * fb_stream_wait_stream) act on the CURRENT device: a binding that serves a box on another device brackets them with
+ * fb_device_get / fb_device_set / fb_device_set(previous), as fastbox_amd/_lib.py on_device() does. */
+int fb_device_get(int* device);
 int fb_device_set(int device);
 
 #ifdef __cplusplus

@@ -41,6 +41,9 @@ class NumpySlabOps(object):
     def set_exp_shift(self, shift):
         self.exp_shift = float(shift)
 
+    def max_real(self, real):
+        return float(real.numpy().max())
+
     def bin_counts(self):
         return hostgeom.bin_counts(self.N, self.g["L"][0], self.bins)
 

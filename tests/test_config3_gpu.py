@@ -82,6 +82,19 @@ def test_config3_chain_against_the_oracle(N):
     assert _close(dx32, want_dx, 3e-5) and _close(vz32, want_vz, 3e-5)
     d = np.abs(np.asarray(ds32) - want_ds)
     assert np.mean(d > 1e-3 * np.std(want_ds)) < 1e-3                 # fraction of voxels whose bracket moved
+    # ... and pinned properly: the oracle's remap, filter and P(k) on the single-precision plan's OWN delta_x and v_z
+    # (float64 arithmetic on the float32 fields).  What is left between the two is the device's arithmetic from the
+    # remap on: a few brackets that flip on a last-bit difference of a shifted coordinate, and float32 rounding of the
+    # transform -- the spectrum of the filtered field at the 1e-5 BASELINE states
+    h_dx, h_vz = np.asarray(dx32), np.asarray(vz32)
+    o_ds = bo.redshift_space_density(geo, h_dx, h_vz, standin.hubble(cosmo, 1.0), 0.)
+    g_ds = np.asarray(ds32)
+    flips = np.abs(g_ds - o_ds) > 1e-5 * np.max(np.abs(o_ds))
+    assert flips.mean() < 2e-6, flips.sum()                            # a few hundred of 1.3e8 voxels at most
+    o_fw = bo.apply_transfer_fn(geo, np.fft.fftn(o_ds), standin.wedge03)
+    _, o_pk, o_err = bo.binned_power_spectrum(geo, np.fft.fftn(o_fw.real), nbins=20)
+    assert np.allclose(pk32[m], o_pk[m], rtol=1e-5, atol=1e-9 * top), np.max(np.abs(pk32[m] / o_pk[m] - 1))
+    assert _close(np.asarray(filt32.real), o_fw.real, 2e-5)
 
 
 def test_redshift_space_eight_cells_per_lane_against_the_oracle():
@@ -112,3 +125,30 @@ def test_redshift_space_eight_cells_per_lane_against_the_oracle():
     want = bo.redshift_space_density(geo, d[sub], v[sub], Hz, 150., _Replay(hostrng.los_noise(N, los_seed)[sub]))
     # libm vs device log / sin / cos differ in the last bits of the noise: a bracket may flip on a handful of cells
     assert np.mean(np.abs(got - want) > 1e-9 * np.max(np.abs(want))) < 1e-5
+
+
+def test_redshift_space_single_precision_plan_at_512_against_the_oracle():
+    """The kernel config 3 is timed on: k_rsd_cells<float, 8> (N = 512, 8 cells per lane, reciprocals instead of the
+    two fp64 divisions, slopes in single precision).  Oracle in float64 on the SAME float32 inputs, 24 x 512 lines of
+    sight with many wraps and crowded / empty cells: outputs agree to float32 rounding except where a last-bit
+    difference of a shifted coordinate moves a bracket -- a handful of cells."""
+    from fastbox_amd import CosmoBox, default_cosmo
+    N, seed = 512, 3
+    box = CosmoBox(cosmo=default_cosmo, box_scale=3e2, nsamp=N, realise_now=False, precision="f32", rng="device", seed=seed)
+    geo = bo.box_geometry(3e2, N)
+    r = np.random.RandomState(6)
+    d = r.normal(size=(N, N, N)).astype(np.float32)
+    v = (2e4 * r.normal(size=(N, N, N))).astype(np.float32)
+    Hz = standin.hubble(standin.cosmology(), 1.0)
+    sub = slice(100, 124)
+    for method in ("linear", "nearest"):
+        got = np.asarray(box.redshift_space_density(delta_x=d, velocity_z=v, sigma_nl=0., method=method))[sub]
+        want = bo.redshift_space_density(geo, d[sub].astype(np.float64), v[sub].astype(np.float64), Hz, 0., method=method)
+        bad = np.abs(got - want) > 2e-6 * np.max(np.abs(want)) + 2e-6 * np.abs(want)
+        assert bad.sum() <= 12, (method, int(bad.sum()))               # of 6.3e6 cells
+    # smooth, small displacements (config 3's regime: |v| / H ~ a few cells): no bracket is anywhere near flipping
+    v2 = (3e2 * r.normal(size=(N, N, N))).astype(np.float32)
+    got = np.asarray(box.redshift_space_density(delta_x=d, velocity_z=v2, sigma_nl=0.))[sub]
+    want = bo.redshift_space_density(geo, d[sub].astype(np.float64), v2[sub].astype(np.float64), Hz, 0.)
+    bad = np.abs(got - want) > 2e-6 * np.max(np.abs(want)) + 2e-6 * np.abs(want)
+    assert bad.sum() <= 12, int(bad.sum())

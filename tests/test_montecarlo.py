@@ -87,3 +87,48 @@ def test_rank_partition_combines_to_the_single_rank_result():
     tot = montecarlo.BandPowerAccumulator.from_raw_sums(n, s1, s2)
     assert tot.n == 30 and np.allclose(tot.mean, one.mean, rtol=1e-13)
     assert np.allclose(tot.covariance(), one.covariance(), rtol=1e-10, atol=1e-13)
+
+
+def _combine_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        acc, kc, _ = montecarlo.run(_FakeBox(), 2, nbins=8, batch=4, rank=rank, world=world)    # rank 2 gets nothing
+        assert (acc.n == 0) == (rank == 2)
+        tot = montecarlo.combine(acc, dist)
+        np.savez(os.path.join(out_dir, "cb%d.npz" % rank), n=tot.n, mean=tot.mean, m2=tot.m2)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_combine_with_a_rank_that_had_no_realisations(tmp_path):
+    """world > realisations: the idle rank enters the all-reduce with zeros of the full length (it used to raise
+    before the collective, leaving the other ranks waiting in it)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_combine_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    one, _, _ = montecarlo.run(_FakeBox(), 2, nbins=8, batch=4)
+    for r in range(3):
+        g = np.load(os.path.join(str(tmp_path), "cb%d.npz" % r))
+        assert int(g["n"]) == 2 and np.allclose(g["mean"], one.mean, rtol=1e-13) and np.allclose(g["m2"], one.m2, atol=1e-12)
+    empty = montecarlo.BandPowerAccumulator.from_raw_sums(0, np.zeros(3), np.zeros((3, 3)))
+    assert empty.n == 0 and empty.mean is None
+
+
+def test_checkpoint_of_another_spectrum_is_refused(tmp_path):
+    ck = str(tmp_path / "mc.npz")
+
+    class PBox(_FakeBox):
+        redshift, scale_factor, amp = 0.0, 1.0, 1.0
+
+        def _power(self, k, a, linear):
+            return self.amp * k ** -1.5
+    montecarlo.run(PBox(), 10, nbins=8, batch=5, checkpoint=ck)
+    other = PBox()
+    other.amp = 1.1
+    with pytest.raises(ValueError):
+        montecarlo.run(other, 10, nbins=8, batch=5, checkpoint=ck)
+    acc, _, _ = montecarlo.run(PBox(), 10, nbins=8, batch=5, checkpoint=ck)          # the same physics resumes
+    assert acc.n == 10

@@ -108,6 +108,86 @@ def test_pipelined_monte_carlo_equals_synchronous_steps(tmp_path, world):
     assert not np.array_equal(g0["sync"][0], g0["sync"][2], equal_nan=True)    # different realisations
 
 
+def _interleave_worker(rank, world, port, out_dir):
+    """Pipelined tickets with other calls of the box between them, and with `_realisation` set by the caller (as a
+    resumed Monte-Carlo run does): no ticket may lose its buffers to a later call."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fastbox_amd.distributed import SlabBox
+        from tests.slab_numpy_ops import NumpySlabOps
+        mk = lambda: SlabBox(standin.DEFAULT_COSMO, box_scale=L, nsamp=N, seed=SEED,
+                             ops_factory=lambda g, P, r: NumpySlabOps(g, P, r),
+                             pk_fn=standin.pk_fn(standin.cosmology(), 1.0))
+        a, b = mk(), mk()
+        order = [0, 3, 6, 1, 9, 12]                      # realisation indices: 0, 3, 6 and 9, 12 would all map to pair 0
+        want = []
+        for i in order:
+            a._realisation = i
+            want.append(a.realise_and_power(nbins=12))
+        a._realisation = 40
+        want_field = a.realise_density().numpy().copy()
+        want_pk = a.binned_power_spectrum(nbins=12)
+        tickets = []
+        for n, i in enumerate(order):
+            b._realisation = i
+            tickets.append(b.realise_and_power(nbins=12, wait=False))
+            if n == 2:                                   # between tickets that are still in flight
+                b._realisation = 40
+                got_field = b.realise_density().numpy().copy()
+                got_pk = b.binned_power_spectrum(nbins=12)
+        got = [t.result() for t in tickets]
+        np.savez(os.path.join(out_dir, "il%d.npz" % rank), want=np.array(want), got=np.array(got),
+                 want_field=want_field, got_field=got_field, want_pk=np.array(want_pk), got_pk=np.array(got_pk))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tickets_survive_interleaved_calls_and_realisation_jumps(tmp_path):
+    mp.spawn(_interleave_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        g = np.load(os.path.join(str(tmp_path), "il%d.npz" % r))
+        assert np.array_equal(g["want"], g["got"], equal_nan=True)
+        assert np.array_equal(g["want_field"], g["got_field"])
+        assert np.array_equal(g["want_pk"], g["got_pk"], equal_nan=True)
+
+
+def _repeat_worker(rank, world, port, out_dir):
+    """A log-normal step whose exponentials leave the floating-point range (here: a shift that flushes every one of
+    them to zero) is formed again with the shift from the field's maximum, on every rank, in all three call forms."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fastbox_amd.distributed import SlabBox
+        from tests.slab_numpy_ops import NumpySlabOps
+        mk = lambda: SlabBox(standin.DEFAULT_COSMO, box_scale=L, nsamp=N, seed=SEED,
+                             ops_factory=lambda g, P, r: NumpySlabOps(g, P, r),
+                             pk_fn=standin.pk_fn(standin.cosmology(), 1.0))
+        a, b = mk(), mk()
+        want = [a.realise_and_power(nbins=12, lognormal=True) for _ in range(3)]
+        a.realise_density()
+        want.append(a.binned_power_spectrum(nbins=12, lognormal=True))
+        assert a.ln_repeats == 0
+        b._ln_shift = 2000.0                             # exp(d - 2000) = 0 in any precision
+        b.ops.set_exp_shift(b._ln_shift)
+        got = [b.realise_and_power(nbins=12, lognormal=True)]
+        tickets = [b.realise_and_power(nbins=12, lognormal=True, wait=False) for _ in range(2)]
+        got += [t.result() for t in tickets]
+        b.realise_density()
+        got.append(b.binned_power_spectrum(nbins=12, lognormal=True))
+        assert b.ln_repeats == 4 and b.ops.exp_shift == 2000.0
+        np.savez(os.path.join(out_dir, "rp%d.npz" % rank), want=np.array(want), got=np.array(got))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_out_of_range_lognormal_step_is_repeated_with_the_exact_shift(tmp_path):
+    mp.spawn(_repeat_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        g = np.load(os.path.join(str(tmp_path), "rp%d.npz" % r))
+        assert np.allclose(g["want"], g["got"], rtol=1e-9, atol=0, equal_nan=True)
+
+
 def test_shell_thresholds_reproduce_digitize():
     """Host tables handed to the device: the threshold form equals np.digitize on every shell
     that is not flagged ambiguous, for several box sizes (edge-on-a-shell cases included)."""

@@ -211,3 +211,99 @@ def test_slab_path_at_1024(P):
     res = run_virtual(boxes, lambda b: b._pk_local(b.delta_x, True, nb), lambda b, kslab: b._pk_finish(kslab, nb).clone())
     h2 = sum(r.cpu().numpy() for r in res)
     assert np.allclose(h2, h, rtol=2e-6)
+
+
+@pytest.fixture(scope="module")
+def single_gpu_2048():
+    """The 2048^3, L = 1000 Mpc realisation of the single-GPU CosmoBox (bench.py's `sizes` box: sigma = 21), reduced on
+    the device: sum, sum of squares, log-normal P(k).  Computed once for the three rank counts below."""
+    import gc
+    from fastbox_amd import CosmoBox, default_cosmo
+    N, L, seed, nb = 2048, 1e3, 13, 20
+    ref = CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, precision="f32", rng="device", seed=seed)
+    dx = ref.realise_density()
+    out = dict(N=N, L=L, seed=seed, nb=nb, sq=ref.engine.sum_real(dx, squared=True), sum=ref.engine.sum_real(dx),
+               ln=ref.binned_power_spectrum(delta_x=ref.lognormal(dx), nbins=nb),
+               gauss=ref.binned_power_spectrum(delta_x=dx, nbins=nb), repeats=ref.lognormal_repeats)
+    del dx
+    ref.engine.close()
+    del ref
+    gc.collect()
+    return out
+
+
+@pytest.mark.parametrize("P", [1, 2, 8])
+def test_slab_path_at_2048(P, single_gpu_2048):
+    """BASELINE config 5's size, the one the >= 6x strong-scaling clause is stated on: 16 points per thread, 128 KiB
+    tiles, exchange-buffer addressing with P dividing those 16 points (fb_slab_x_generate, fb_slab_turnaround,
+    fb_slab_x_bin; then fb_slab_inverse_packed / fb_slab_forward_packed on fresh ranks), as P virtual ranks on one
+    GPU against the single-GPU box: the field through sum and sum of squares, the log-normal P(k) at 1e-5."""
+    import gc
+    import torch
+    from fastbox_amd import default_cosmo, hostgeom
+    from fastbox_amd.distributed import HipSlabOps, SlabBox, run_virtual
+    w = single_gpu_2048
+    N, L, seed, nb = w["N"], w["L"], w["seed"], w["nb"]
+    assert w["repeats"] == 0
+
+    def ranks():
+        bs = [SlabBox(default_cosmo, box_scale=L, nsamp=N, precision="f32", seed=seed, rank=r, world=P,
+                      ops_factory=lambda g, PP, rr: HipSlabOps(g, PP, rr, precision="f32", device=0)) for r in range(P)]
+        for b in bs:
+            b._pk_setup(nb, None)
+        return bs
+
+    def sums(fields):      # fp64 accumulation without an fp64 copy of the slab
+        sq = sum(float(torch.linalg.vector_norm(f.reshape(-1), 2, dtype=torch.float64)) ** 2 for f in fields)
+        return sq, sum(float(torch.sum(f, dtype=torch.float64)) for f in fields)
+
+    def spectrum(h):
+        s1, s2, esum = h[0:2 * nb:2], h[1:2 * nb:2], h[2 * nb]
+        assert hostgeom.lognormal_sums_in_range(boxes[0].ops.bin_counts(), s1, s2, esum)
+        mean = esum / float(N) ** 3
+        return hostgeom.finish_bins(boxes[0].ops.bin_counts(), s1 / mean ** 2, s2 / mean ** 4, boxes[0].boxfactor)
+
+    boxes = ranks()
+    assert boxes[0]._ln_shift == hostgeom.lognormal_shift(boxes[0]._sigma2, float(N) ** 3)
+
+    def turn(b, recv):
+        b._res = b.ops.new_results(2 * nb + 1)
+        b.delta_x = b.ops.new_real()
+        b._send2 = b._kslab if recv is b._xbuf else b._xbuf
+        b.ops.turnaround(recv, b._half, b.delta_x, b._send2, True, b._res[2 * nb:])
+        return b._send2
+    run_virtual(boxes, lambda b: b._gen_local(), turn)
+    assert all(b.ops.fused_exchange for b in boxes)               # P | 16: the y passes address the exchange buffers
+    got_sq, got_sum = sums([b.delta_x for b in boxes])
+    assert np.isclose(got_sq, w["sq"], rtol=1e-6) and abs(got_sum - w["sum"]) < 1e-6 * np.sqrt(w["sq"] * float(N) ** 3)
+    res = run_virtual(boxes, lambda b: b._send2, lambda b, kslab: b._pk_finish(kslab, nb).clone())
+    h = sum(r.cpu().numpy() for r in res)
+    pk, err = spectrum(h)
+    want = w["ln"]
+    m = ~np.isnan(want[1])
+    assert np.array_equal(np.isnan(pk), np.isnan(want[1])) and np.array_equal(np.isnan(pk), np.isnan(w["gauss"][1]))
+    assert np.allclose(pk[m], want[1][m], rtol=1e-5, atol=0), np.max(np.abs(pk[m] / want[1][m] - 1))
+    assert np.all(np.abs(err[m] - want[2][m]) <= 1e-4 * (np.abs(want[2][m]) + np.abs(want[1][m])))
+    # the un-fused pieces on fresh ranks: the same realisation again, the same sums
+    del boxes, res
+    gc.collect()
+    torch.cuda.empty_cache()
+    boxes = ranks()
+    reals = run_virtual(boxes, lambda b: b._gen_local(), lambda b, recv: b._gen_finish(recv))
+    sq2, sum2 = sums(reals)
+    assert np.isclose(sq2, w["sq"], rtol=1e-6)
+    del reals
+    res = run_virtual(boxes, lambda b: b._pk_local(b.delta_x, True, nb), lambda b, kslab: b._pk_finish(kslab, nb).clone())
+    h2 = sum(r.cpu().numpy() for r in res)
+    assert np.allclose(h2, h, rtol=2e-6)
+    if P == 1:          # the public entry point on one rank, Gaussian and log-normal, pipelined and not
+        b = boxes[0]
+        b._realisation = 0
+        kc, pk1, err1 = b.realise_and_power(nbins=nb, lognormal=True)
+        assert np.allclose(pk1[m], want[1][m], rtol=1e-5, atol=0) and b.ln_repeats == 0
+        b._realisation = 0
+        kc, pk0, err0 = b.realise_and_power(nbins=nb, lognormal=False, wait=False).result()
+        assert np.allclose(pk0[m], w["gauss"][1][m], rtol=1e-5, atol=0)
+    del boxes, res
+    gc.collect()
+    torch.cuda.empty_cache()
