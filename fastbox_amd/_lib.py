@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfastbox_hip.so")
+# FASTBOX_HIP_LIB: another build of the same sources (tuning variants, tools/build_variants.sh); default: the in-tree library
+LIB_PATH = os.environ.get("FASTBOX_HIP_LIB") or os.path.join(_HERE, "lib", "libfastbox_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 c_void_p, c_int, c_double, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
@@ -89,8 +90,8 @@ SIGNATURES = {
     "fb_slab_x_pass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fb_slab_x_generate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_u64, c_u64, c_void_p]),
     "fb_slab_x_bin": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "fb_set_tuning": (c_int, [c_void_p, c_int, c_int, c_int]),
     "fb_set_plane_batching": (c_int, [c_void_p, c_int, c_int]),
+    "fb_set_pass_schedule": (c_int, [c_void_p, c_int, c_int, c_int]),
     "fb_set_exp_shift": (c_int, [c_void_p, ctypes.c_double]),
     "fb_debug_strided_pass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fb_debug_read_stamps": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), c_i64]),

@@ -653,12 +653,21 @@ class CosmoBox(object):
                 else:
                     shift = hostgeom.lognormal_shift_exact(eng.max_real(src), nvox)
                 nb_, bin_args = bins.size, (bins, thr, amb)
+                # (the repeat must not keep the field alive: a loop that queues hundreds of spectra drops each delta_x
+                # at once, and its buffer goes back to the pool; a field that is gone is drawn again from its recipe)
+                wsrc, regen = weakref.ref(src), getattr(src, "_regenerate", None)
 
-                def redo(src=src):
+                def redo():
+                    field = wsrc()
+                    if field is None:
+                        if regen is None:
+                            raise FloatingPointError("log-normal P(k): the exponentials left the plan's floating-point "
+                                                     "range and the field is no longer there to repeat the step")
+                        field = regen()
                     self.lognormal_repeats += 1
                     eng.set_bins(*bin_args)
-                    exact = hostgeom.lognormal_shift_exact(eng.max_real(src), nvox)     # (materialises a pending field)
-                    res2, _ = eng.power_fused(src, pre_exp=True, exp_shift=exact)
+                    exact = hostgeom.lognormal_shift_exact(eng.max_real(field), nvox)   # (materialises a pending field)
+                    res2, _ = eng.power_fused(field, pre_exp=True, exp_shift=exact)
                     return eng.fetch_results(res2, nb_)
             if isinstance(src, PendingDensity) and not src.materialised and src._pending is not None:
                 res, real = eng.power_pending(src._pending, pre_exp=ln, exp_shift=shift, keep_field=keep_field)     # z passes fused

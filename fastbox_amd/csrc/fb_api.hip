@@ -642,10 +642,11 @@ int fb_debug_strided_pass(fb_plan* p, void* half, int axis, int mode, void* stre
     return FB_DISPATCH(p, fbi_debug_pass_f32(p, half, axis, mode, s), fbi_debug_pass_f64(p, half, axis, mode, s));
 }
 
-int fb_set_tuning(fb_plan* p, int stagger_plain, int stagger_gen, int stagger_bin) {
+int fb_set_pass_schedule(fb_plan* p, int plain, int generator, int binning) {
     FB_REQUIRE(p, "null pointer");
-    FB_USE_DEVICE(p);
-    p->stagger[0] = stagger_plain; p->stagger[1] = stagger_gen; p->stagger[2] = stagger_bin;
+    FB_REQUIRE(plain >= -1 && plain <= 1 && generator >= -1 && generator <= 1 && binning >= -1 && binning <= 1,
+               "schedule: 0 (one workgroup per tile), 1 (resident workgroups) or -1 (by grid size)");
+    p->pass_schedule[0] = plain; p->pass_schedule[1] = generator; p->pass_schedule[2] = binning;
     return FB_OK;
 }
 int fb_set_exp_shift(fb_plan* p, double shift) {

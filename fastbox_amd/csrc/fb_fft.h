@@ -153,18 +153,19 @@ typedef unsigned int fb_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)FB_BUF_RANGE, 0x00020000);
 }
-template <int AUX = 0> __device__ __forceinline__ cx<float> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, const cx<float>*) {
-    return __builtin_bit_cast(cx<float>, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, AUX));
+// soff: wave-uniform byte offset (a scalar register of the instruction; not part of the range check)
+template <int AUX = 0> __device__ __forceinline__ cx<float> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const cx<float>*) {
+    return __builtin_bit_cast(cx<float>, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, AUX));
 }
-template <int AUX = 0> __device__ __forceinline__ cx<double> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, const cx<double>*) {
-    return __builtin_bit_cast(cx<double>, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, AUX));
+template <int AUX = 0> __device__ __forceinline__ cx<double> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const cx<double>*) {
+    return __builtin_bit_cast(cx<double>, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX));
 }
 // AUX: cache policy bits of the instruction (0 default, 2 = nt: streaming data that nothing re-reads soon)
-template <int AUX = 0> __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, cx<float> v) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fb_u32x2, v), r, (int)voff, 0, AUX);
+template <int AUX = 0> __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, cx<float> v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fb_u32x2, v), r, (int)voff, (int)soff, AUX);
 }
-template <int AUX = 0> __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, cx<double> v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fb_u32x4, v), r, (int)voff, 0, AUX);
+template <int AUX = 0> __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, cx<double> v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fb_u32x4, v), r, (int)voff, (int)soff, AUX);
 }
 
 constexpr int fb_min(int a, int b) { return a < b ? a : b; }

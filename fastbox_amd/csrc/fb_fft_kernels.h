@@ -68,8 +68,9 @@ template <typename T> struct StridedArgs {
     int ntx;                 // tiles per outer index = ceil(ncols / TZ)      (set by the launcher)
     int ntiles;              // ntx * (number of outer indices)               (set by the launcher)
     int drop_io;             // tuning aid: do all the arithmetic but no global loads/stores
-    int stagger;             // first-generation workgroups [num_cu, 2 num_cu) sleep this many x64 cycles
-    int num_cu;
+    int wide;                // a line's last point lies 4 GiB or more behind its first: every point gets its own 64-bit base
+                             // (else one base per tile and a 32-bit scalar offset per point)          (set by the launcher)
+    int ntx_shift;           // log2(ntx) if ntx is a power of two, else -1                              (set by the launcher)
     // Exchange-buffer addressing of the slab-decomposed transform (all zero = the plain layout on both sides).
     // A line of the blocked side is cut into 2^blk_shift ... pieces: point k lives at
     // (k / B) * blk_stride + (k % B) * stride with B = (N / elements-per-thread) << blk_shift points per piece,
@@ -102,15 +103,29 @@ template <typename T> struct StridedOp {
     int amb[8];
 };
 
-// Persistent workgroups: each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and issues
-// the global loads of its next tile before transforming the current one, so that HBM requests
-// stay in flight through the LDS exchanges and the fused epilogue.
-// PERSIST = false: one tile per workgroup, two workgroups per CU (<= 64 VGPRs at 1024 threads).
-template <typename T, int N, int MODE, int PERSIST>   // 0: one tile per workgroup; 1: loop + register prefetch; 2: loop only
+// PERSIST = 0: one tile per workgroup (the grid has as many workgroups as tiles).
+// PERSIST = 1: resident workgroups (as many as fit on the chip) that each walk the tiles blockIdx.x, blockIdx.x +
+// gridDim.x, ... and issue the global loads of their NEXT tile as early as the registers allow -- into the very
+// registers the current tile has just left: a plain pass right behind its stores, the binning pass as soon as |X|^2
+// has been staged in LDS (the whole binning epilogue then runs under the next tile's memory latency).  No register is
+// added (still <= 64 VGPRs, two 1024-thread workgroups per CU), and the workgroup's hand-over -- store drain, exit,
+// dispatch of the successor: 3-6 k of a tile's 16-23 k cycles, tools/phase_timeline.py -- is gone.
+// (Round 1's persistent form prefetched into a SECOND register set, which costs the second resident workgroup, and
+// walked the tiles so that one workgroup met all the heavy generator tiles; both measured slower and are removed.)
+// BLK: the exchange-buffer addressing of the slab-decomposed transform (StridedArgs::blk_*); plain passes only.
+//
+// Scalar instructions: a CU issues ONE scalar-ALU instruction per cycle for all its waves (tools/salu_rate.hip:
+// 1.02-1.08 cycles per instruction whatever the number of waves; vector instructions 0.65), and a strided pass is
+// mostly wave-uniform bookkeeping -- tile coordinates, 64-bit bases, buffer descriptors.  Round 2's form spent ~300
+// scalar instructions per wave and tile on it (16 waves: 4.8 k of a plain tile's 5.3 k cycles without memory traffic:
+// the pass was bound by its scalar unit, not by its butterflies).  Hence: one descriptor per tile and a 32-bit scalar
+// offset per point where the line fits 4 GiB, shifts instead of divisions for power-of-two tile counts, the slab
+// addressing compiled only into the kernels that use it.
+template <typename T, int N, int MODE, int PERSIST, bool BLK = false>
 __global__ __launch_bounds__(tile_cols<T>(N) * (N / strided_elems(N)),
-                             PERSIST == 1 ? 1 : fb_min(8, fb_max(1, strided_wg_per_cu<T>(N)
-                                                                     * tile_cols<T>(N) * (N / strided_elems(N)) / 256)))
+                             fb_min(8, fb_max(1, strided_wg_per_cu<T>(N) * tile_cols<T>(N) * (N / strided_elems(N)) / 256)))
 void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
+    static_assert(!BLK || MODE == SMODE_PLAIN, "slab addressing: plain passes only");
     constexpr int E = strided_elems(N);
     constexpr int TPL = N / E;
     constexpr int TZ = tile_cols<T>(N);
@@ -125,11 +140,6 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     const int tid = threadIdx.x;
     const int c = tid % TZ;
     const int t = tid / TZ;
-    // Two workgroups share a CU and, started together, stay in lockstep (same period): both wait
-    // for HBM, then both compute.  Delaying the second resident generation once by about half a
-    // period makes one compute while the other waits, for the whole launch.
-    if (a.stagger > 0 && (int)blockIdx.x >= a.num_cu && (int)blockIdx.x < 2 * a.num_cu)
-        for (int q = 0; q < a.stagger; q += 64) __builtin_amdgcn_s_sleep(64);
     // The tables (twiddles; bin thresholds) are first needed after the first LDS exchange, whose
     // barrier also publishes them: in the one-tile-per-workgroup form they are fetched AFTER the
     // tile's own loads have been issued, and no barrier stands between a wave's loads and its
@@ -138,11 +148,10 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         for (int i = tid; i < N; i += NT) twl[i] = a.tw[i];
         if constexpr (smode_bins(MODE)) {
             for (int i = tid; i < NW * 2 * op.nbins; i += NT) acc[i] = 0.0;
-            for (int i = tid; i < op.nbins; i += NT) lthr[i] = op.thr[i];
+            for (int i = tid; i < ((op.nbins + 63) & ~63); i += NT) lthr[i] = i < op.nbins ? op.thr[i] : 0x7fffffff;
         }
     };
     if constexpr (PERSIST) load_tables();
-    TileLayout<T, TZ> lay{tile, c};
 #ifdef FB_STAMPS      // diagnostic build only: phase time stamps of every workgroup (tools/stamps.py)
     long long* stamp = (smode_bins(MODE))
         ? reinterpret_cast<long long*>(op.partial + (size_t)2 * op.nbins * op.partial_stride) + (size_t)blockIdx.x * 32
@@ -166,22 +175,54 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     const long long tbase = (long long)t0 * a.stride;
     const unsigned loff = (unsigned)(((long long)(t - t0) * a.stride + c) * (long long)sizeof(cx<T>));
     const long long estep = (long long)TPL * a.stride;
-    // offset of a thread's e-th point (e is a compile-time constant after unrolling, the rest is wave-uniform)
-    auto eoff = [&](int e, int blocked) -> long long {
+    const unsigned estep_b = (unsigned)(estep * (long long)sizeof(cx<T>));       // meaningful when !a.wide
+    // offset of a thread's e-th point in the slab addressing (e is a compile-time constant after unrolling, the rest is
+    // wave-uniform)
+    [[maybe_unused]] auto eoff = [&](int e, int blocked) -> long long {
         return blocked ? (long long)(e >> a.blk_shift) * a.blk_stride + (long long)(e & ((1 << a.blk_shift) - 1)) * estep
                        : (long long)e * estep;
+    };
+    // the E points of this thread from / to the tile whose first row (this wave's) starts at src / dst
+    auto load_rows = [&](cx<T> (&r)[E], const cx<T>* src, const unsigned voff) {
+        constexpr int AUX = smode_bins(MODE) ? FB_BIN_LOAD_AUX : 0;
+        if constexpr (BLK) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) r[e] = buf_load<AUX>(make_rsrc(src + eoff(e, a.blk_in)), voff, 0u, src);
+        } else if (!a.wide) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(src);
+#pragma unroll
+            for (int e = 0; e < E; ++e) r[e] = buf_load<AUX>(rs, voff, (unsigned)e * estep_b, src);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) r[e] = buf_load<AUX>(make_rsrc(src + (long long)e * estep), voff, 0u, src);
+        }
+    };
+    auto store_rows = [&](cx<T>* dst, const unsigned voff, const cx<T> (&r)[E], const T scale) {
+        constexpr int AUX = MODE == SMODE_GEN ? FB_GEN_STORE_AUX : 0;
+        if constexpr (BLK) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) buf_store<AUX>(make_rsrc(dst + eoff(e, a.blk_out)), voff, 0u, cscale(r[e], scale));
+        } else if (!a.wide) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(dst);
+#pragma unroll
+            for (int e = 0; e < E; ++e) buf_store<AUX>(rs, voff, (unsigned)e * estep_b, cscale(r[e], scale));
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) buf_store<AUX>(make_rsrc(dst + (long long)e * estep), voff, 0u, cscale(r[e], scale));
+        }
     };
     const long long out_outer = a.out_outer_stride ? a.out_outer_stride : a.outer_stride;
 
     cx<T> v[E];
-    [[maybe_unused]] cx<T> vn[E];
     [[maybe_unused]] int wb_lo = 0, wb_hi = 0, wb_edge = 0x7fffffff;   // BIN: this wave's bins (see epilogue)
     [[maybe_unused]] bool wb_ok = false, wb_rng = false;
     // BIN: lane l keeps thresholds l, l + 64, ... (FB_MAX_BINS = 256: four registers), fetched before the tile so that
     // one memory latency covers both; "number of thresholds <= n^2" is then a compare and a ballot per 64 thresholds
     // instead of a binary search of dependent scalar loads (5.8 k of a workgroup's 20 k cycles, tools/stamps.py)
+    // (resident form: the thresholds are read from their LDS copy when a tile needs them -- the table was published once
+    // before the tile loop, and four registers held across it would spill)
     [[maybe_unused]] int thrv[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-    if constexpr (smode_bins(MODE)) {
+    if constexpr (smode_bins(MODE) && !PERSIST) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (r * 64 < op.nbins) { const int q = r * 64 + (tid & 63); thrv[r] = q < op.nbins ? op.thr[q] : 0x7fffffff; }
@@ -190,19 +231,31 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         int b = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (r * 64 < op.nbins) b += __builtin_popcountll(__ballot(thrv[r] <= n2));
+            if (r * 64 < op.nbins) {
+                int th;
+                if constexpr (PERSIST) th = lthr[r * 64 + (tid & 63)];      // padded with INT_MAX to a multiple of 64
+                else th = thrv[r];
+                b += __builtin_popcountll(__ballot(th <= n2));
+            }
         return b;
     };
     // tile number -> (tile column bx, outer index by).  Speed only: nothing depends on the placement.
+    [[maybe_unused]] const int rot_rows = (int)gridDim.x >= a.ntx ? (int)gridDim.x / a.ntx : 1;   // rows per sweep of a resident grid
     auto place = [&](int id, int& bx, int& by) {
-        bx = id % a.ntx;
-        by = id / a.ntx;
+        const bool p2 = a.ntx_shift >= 0;                     // (a division costs ~45 scalar instructions)
+        bx = p2 ? (id & (a.ntx - 1)) : id % a.ntx;
+        by = p2 ? (id >> a.ntx_shift) : id / a.ntx;
 #ifndef FB_NO_TILE_ROTATE
         // Workgroup b runs on XCD b % 8 and ntx is a multiple of 8 at every power-of-two size, so without this every
         // row's tile 0 -- the self-mirrored planes of the generator, twice the draws of any other tile -- would land on
         // XCD 0, which then finishes 60 % after the other seven (tools/phase_timeline.py).  Rotating the tile index by
         // the row number deals the heavy tiles round all eight XCDs.
-        bx = (bx + by) % a.ntx;
+        // (resident workgroups: + the number of the sweep, so that a workgroup's own tiles -- ids gridDim.x apart, which
+        // would otherwise all have the same column -- also take every column in turn.  A function of `by` alone, so the
+        // map tile id -> tile stays one to one whatever the grid size.)
+        int rot = bx + by;
+        if constexpr (PERSIST) rot += by / rot_rows;
+        bx = p2 ? (rot & (a.ntx - 1)) : rot % a.ntx;
 #endif
 #ifndef FB_NO_XCD_PAIR
         if constexpr (TZ * sizeof(cx<T>) < 128) {
@@ -217,28 +270,32 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 #endif
     };
     int tile_id = blockIdx.x;
-    if constexpr (MODE != SMODE_GEN && PERSIST == 1) {          // the launcher guarantees gridDim.x <= ntiles
-        int bx0, by0;
-        place(tile_id, bx0, by0);
-        const cx<T>* src = a.in + ((long long)by0 * a.outer_stride + bx0 * TZ + tbase);
-        const unsigned voff = bx0 * TZ + c < a.ncols ? loff : FB_BUF_OOB;
-#pragma unroll
-        for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + eoff(e, a.blk_in)), voff, src);
-        if constexpr (!smode_bins(MODE)) {
-            // E stores that the range check discards: they make the memory-op queue at loop entry
-            // look like the queue at the back edge (E loads, then E stores), so that the compiler's
-            // merged s_waitcnt for "previous prefetch has landed" is vmcnt(E) on both paths instead
-            // of a vmcnt(0) that would also drain the previous tile's stores every iteration.
-#pragma unroll
-            for (int e = 0; e < E; ++e) buf_store(make_rsrc(a.out), FB_BUF_OOB, cx<T>{0, 0});
-        }
-    }
+    // loads of tile `id` into v[] (ids past the last tile: every lane gets the out-of-range offset, which the buffer
+    // range check turns into "no access" -- no branch around the loads, so the compiler's in-order vmcnt bookkeeping
+    // sees the same queue on every path)
+    [[maybe_unused]] auto load_tile = [&](int id) {
+        int lbx, lby;
+        place(id, lbx, lby);
+        const cx<T>* src = a.in + ((long long)lby * a.outer_stride + lbx * TZ + tbase);
+        const unsigned voff = (id < a.ntiles && lbx * TZ + c < a.ncols && !a.drop_io) ? loff : FB_BUF_OOB;
+        load_rows(v, src, voff);
+    };
+    if constexpr (MODE != SMODE_GEN && PERSIST) load_tile(tile_id);     // the launcher guarantees gridDim.x <= ntiles
     do {    // PERSIST: tiles blockIdx.x, blockIdx.x + gridDim.x, ...; otherwise exactly one tile
+        // Resident form: everything a tile derives from the lane's coordinates (LDS addresses of every stage, mode
+        // numbers, row pointers: dozens of values) is loop-invariant, and hoisted out of the tile loop it would stay
+        // live across it -- 10 to 90 registers spilled, and reloads from scratch that queue behind the next tile's
+        // loads.  An opaque per-tile copy of the thread index makes all of it per-tile again, recomputed where it is
+        // used, as in the one-tile form.  (Shadows the kernel-scope tid, c, t on purpose.)
+        int tid_tile = tid;
+        if constexpr (PERSIST) asm volatile("" : "+v"(tid_tile));
+        const int tid = tid_tile, c = tid % TZ, t = tid / TZ;
         int bx, by;
         place(tile_id, bx, by);
         const int col = bx * TZ + c;
         const bool valid = col < a.ncols;
         const long long ubase = (long long)by * a.outer_stride + bx * TZ;
+        const TileLayout<T, TZ> layf{tile, c};
 
         if constexpr (MODE == SMODE_GEN) {
             // generator: thread pair j holds the modes k_x = t + j TPL (< N/2) and k_x + N/2, which share one
@@ -418,36 +475,19 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) v[e] = cx<T>{0, 0};
             }
-        } else if constexpr (PERSIST != 1) {
+        } else if constexpr (!PERSIST) {
             const cx<T>* src = a.in + ubase + tbase;
             const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                if constexpr (smode_bins(MODE)) v[e] = buf_load<FB_BIN_LOAD_AUX>(make_rsrc(src + eoff(e, a.blk_in)), voff, src);
-                else v[e] = buf_load(make_rsrc(src + eoff(e, a.blk_in)), voff, src);
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = vn[e];
-            // Prefetch the next tile.  Issued unconditionally (past the last tile every lane
-            // gets the out-of-range offset, which the buffer range check turns into "no access"):
-            // a branch here makes the compiler's in-order vmcnt bookkeeping pessimistic and it
-            // then waits for these loads before the current tile's first butterfly.
-            const int nxt = tile_id + gridDim.x;
-            int nbx, nby;
-            place(nxt, nbx, nby);
-            const cx<T>* src = a.in + ((long long)nby * a.outer_stride + nbx * TZ + tbase);
-            const unsigned voff = (nxt < a.ntiles && nbx * TZ + c < a.ncols) ? loff : FB_BUF_OOB;
-#pragma unroll
-            for (int e = 0; e < E; ++e) vn[e] = buf_load(make_rsrc(src + eoff(e, a.blk_in)), voff, src);
-        }
+            load_rows(v, src, voff);
+        }       // (PERSIST: v[] was loaded ahead -- before the loop, or while the previous tile was being finished)
 #ifdef FB_STAMPS
         FB_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FB_STAMP(2);
 #endif
-        if constexpr (PERSIST) __syncthreads();   // LDS of the previous tile's epilogue is free again
-        else load_tables();
+        if constexpr (!PERSIST) load_tables();
+        else if constexpr (smode_bins(MODE)) __syncthreads();   // the previous tile's binning has read its |X|^2 out of LDS
+        // (plain and generator passes: a tile's last LDS access is the read that ends its last exchange, behind a barrier)
         if constexpr (smode_bins(MODE) && (64 * E) % TZ == 0 && (N / 2) % ((64 * E) / TZ) == 0 && (TZ % E == 0 || E % TZ == 0)) {
             // The bins of this wave's block of the tile depend on the tile's coordinates only: look
             // them up now, while the tile's data is still on its way from HBM.
@@ -467,17 +507,20 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             wb_ok = wb_hi - wb_lo <= 1;
             wb_edge = 0x7fffffff;                   // first n^2 of bin wb_hi = thr[wb_lo], from the lane that holds it
             if (wb_ok && wb_hi > wb_lo) {
+                if constexpr (PERSIST) wb_edge = lthr[wb_lo];
+                else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if ((wb_lo >> 6) == r) wb_edge = __builtin_amdgcn_readlane(thrv[r], wb_lo & 63);
+                    for (int r = 0; r < 4; ++r)
+                        if ((wb_lo >> 6) == r) wb_edge = __builtin_amdgcn_readlane(thrv[r], wb_lo & 63);
+                }
             }
         }
         FB_STAMP(3);
-        if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
-        else if constexpr (smode_bins(MODE)) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);
+        if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, layf);
+        else if constexpr (smode_bins(MODE)) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, layf);
         else {
-            if (sign < 0) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, lay);
-            else          fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
+            if (sign < 0) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, layf);
+            else          fft_stages<T, N, E, +1, 1, 1>(v, t, twl, layf);
         }
         FB_STAMP(4);
         if constexpr (MODE == SMODE_BINF) {
@@ -489,7 +532,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                 for (int e = 0; e < E; ++e) {
                     const int kx = t + e * TPL;
                     const long long idx = ((long long)kx * op.g.NR + kyf) * op.g.NZP + col;
-                    const T m = filter_value<T>(op.filt, op.g, kx, kyf, col, idx, op.kperp_tab[(long long)kx * N + kyf]);
+                    const T m = filter_value<T, false>(op.filt, op.g, kx, kyf, col, idx, op.kperp_tab[(long long)kx * N + kyf]);
                     v[e] = cx<T>{nan_to_num(v[e].x * m), nan_to_num(v[e].y * m)};
                 }
             }
@@ -503,16 +546,15 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             // store == 2: the caller wants the filtered FIELD (apply_transfer_fn's product, box.py:381): its inverse
             // transform starts with this very x line, so it is taken here, on the registers that hold the filtered
             // line, and the pass that would re-read and re-write the whole spectrum for it never runs
-            if (op.store == 2) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, lay);
+            if (op.store == 2) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, layf);
         }
         if constexpr (!smode_bins(MODE) || MODE == SMODE_BINF) {
             cx<T>* dst = a.out + ((long long)by * out_outer + bx * TZ) + tbase;
             const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                if constexpr (MODE == SMODE_GEN) buf_store<FB_GEN_STORE_AUX>(make_rsrc(dst + eoff(e, a.blk_out)), voff, cscale(v[e], a.scale));
-                else buf_store(make_rsrc(dst + eoff(e, a.blk_out)), voff, cscale(v[e], a.scale));
-            }
+            store_rows(dst, voff, v, a.scale);
+            // resident workgroup, plain pass: the next tile's loads go out right behind the stores (a store has read its
+            // registers when it issues), so its memory latency runs beside this tile's store drain
+            if constexpr (PERSIST && MODE == SMODE_PLAIN) load_tile(tile_id + (int)gridDim.x);
         }
         if constexpr (smode_bins(MODE)) {
             // Re-stage p = |X|^2 through LDS so that each lane bins E consecutive elements of
@@ -529,6 +571,9 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             }
 #pragma unroll
             for (int e = 0; e < E; ++e) ptile[(t + e * TPL) * TZ + c] = pq[e];
+            // resident workgroup: v[] is free from here on -- the next tile's loads are issued now and the binning below
+            // runs under their latency
+            if constexpr (PERSIST) load_tile(tile_id + (int)gridDim.x);
             __syncthreads();
             FB_STAMP(5);
             double* row = acc + (size_t)(tid >> 6) * 2 * nb;
@@ -610,18 +655,18 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                 }
             }
             if (!done) {
-            T pv[E];
-            int n2v[E];
-            int n2lo = 0x7fffffff, n2hi = -1;
-#pragma unroll
-            for (int q = 0; q < E; ++q) {
-                pv[q] = ptile[off0 + q];
+            // (this path is rare; it keeps nothing per element in registers -- a mode's n^2 is recomputed and its |X|^2
+            // re-read from LDS where needed -- because in the resident form the next tile's loads are in flight in v[])
+            auto mode_n2 = [&](int q) -> int {                  // n^2 of the lane's q-th element, -1: not a stored mode
                 const int kx = (off0 + q) / TZ, kz = col0 + (off0 + q) % TZ;
                 const int mx = mode_of(kx, N);
-                const bool ok = kz < a.ncols && !(pk0 && kz == 0);
-                const int n2 = mx * mx + my2 + kz * kz;
-                n2v[q] = ok ? n2 : -1;
-                if (ok) { n2lo = n2 < n2lo ? n2 : n2lo; n2hi = n2 > n2hi ? n2 : n2hi; }
+                return (kz < a.ncols && !(pk0 && kz == 0)) ? mx * mx + my2 + kz * kz : -1;
+            };
+            int n2lo = 0x7fffffff, n2hi = -1;
+#pragma unroll 1
+            for (int q = 0; q < E; ++q) {
+                const int n2 = mode_n2(q);
+                if (n2 >= 0) { n2lo = n2 < n2lo ? n2 : n2lo; n2hi = n2 > n2hi ? n2 : n2hi; }
             }
             const bool any_ok = n2hi >= 0;
             const int blo = any_ok ? shell_bin(lthr, nb, n2lo) : 0, bhi = any_ok ? shell_bin(lthr, nb, n2hi) : 0;
@@ -631,12 +676,13 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                 // a lane's modes fall into bin blo or blo+1: one compare against the edge
                 const int edge = (any_ok && blo < nb) ? lthr[blo] : 0x7fffffff;   // first n^2 of bin blo+1
                 double s1 = 0.0, s2 = 0.0, u1 = 0.0, u2 = 0.0;
-#pragma unroll
+#pragma unroll 1
                 for (int q = 0; q < E; ++q) {
                     const int kz = col0 + (off0 + q) % TZ;
-                    const double w = (n2v[q] < 0) ? 0.0 : ((kz == 0 || kz == (N >> 1)) ? 1.0 : 2.0);
-                    const double p = (double)pv[q];
-                    const bool up = n2v[q] >= edge;
+                    const int n2 = mode_n2(q);
+                    const double w = (n2 < 0) ? 0.0 : ((kz == 0 || kz == (N >> 1)) ? 1.0 : 2.0);
+                    const double p = (double)ptile[off0 + q];
+                    const bool up = n2 >= edge;
                     s1 += up ? 0.0 : w * p; s2 += up ? 0.0 : w * p * p;
                     u1 += up ? w * p : 0.0; u2 += up ? w * p * p : 0.0;
                 }
@@ -645,15 +691,15 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             } else {
                 // rare: a lane's own modes straddle an edge (or touch a shell that needs the
                 // exact |k|): bin element by element
-#pragma unroll
+#pragma unroll 1
                 for (int q = 0; q < E; ++q) {
                     const int kx = (off0 + q) / TZ, kz = col0 + (off0 + q) % TZ;
-                    const int n2 = n2v[q];
+                    const int n2 = mode_n2(q);
                     int bb = n2 >= 0 ? shell_bin(lthr, nb, n2) : nb;
                     for (int z = 0; z < op.namb; ++z)
                         if (n2 >= 0 && op.amb[z] == n2) bb = bin_exact(op.bins, nb, kmag_exact(op.g, kx, ky, kz));
                     const double w = (kz == 0 || kz == (N >> 1)) ? 1.0 : 2.0;
-                    const double p = (double)pv[q];
+                    const double p = (double)ptile[off0 + q];
                     wave_flush(bb, w * p, w * p * p, n2 >= 0 && bb < nb, row);
                 }
             }

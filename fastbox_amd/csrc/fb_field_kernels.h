@@ -270,13 +270,15 @@ __device__ __forceinline__ void wave_flush(int b, float s1, float s2, bool have,
 // block partial sums of f(x); OP 0: x, 1: x^2, 2: exp(x - shift) (also written to out), 3: block maxima of x instead of sums
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void k_reduce_real(const T* __restrict__ in, T* __restrict__ out, long long n,
-                                                      double* __restrict__ partial, T shift = 0) {
+                                                      double* __restrict__ partial, double shift = 0) {
     __shared__ double ws[4];
     double s = OP == 3 ? -1.7976931348623157e308 : 0.0;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
         T x = in[q];
         if (OP == 1) x = x * x;
-        if (OP == 2) { x = exp(x - shift); out[q] = x; }
+        // (difference and exponential in double: rounded to single precision, x - shift ~ -100 would carry 4e-6 of
+        // absolute error into the exponent -- 40 times the 1e-7 that exp(x) of the stored value has; streaming kernel)
+        if (OP == 2) { x = (T)exp((double)x - shift); out[q] = x; }
         if (OP == 3) s = (double)x > s ? (double)x : s;        // (a NaN never wins: the maximum of the finite values)
         else s += (double)x;
     }
@@ -340,11 +342,13 @@ struct FilterSpec {
 // BEAM_HIGHPASS: (1 - exp(-0.5 (|kpar|/p0)^p2)) [p0 > 0]  *  exp(-0.5 (kperp/p1)^2) [p1 > 0]
 // WEDGE       : 0 where |kpar| < p0 * kperp + p1, else 1
 // TOPHAT      : 3 (sin x - x cos x)/x^3, x = |k| p0   (NaN at k=0 -> 0 after nan_to_num)
-template <typename T>
+// TOPHAT = false: a caller that never sees that kind (the fused filtering pass of the strided FFT kernel, whose
+// registers the sine / cosine evaluation would not fit beside the line) compiles without it.
+template <typename T, bool TOPHAT = true>
 __device__ __forceinline__ T filter_value(const FilterSpec& f, const KGeom& g, int i, int j, int l, long long idx,
                                           double kperp_row) {
     if (f.kind == FILT_TABLE) return reinterpret_cast<const T*>(f.table)[idx];
-    if (f.kind == FILT_TOPHAT) {
+    if (TOPHAT && f.kind == FILT_TOPHAT) {
         const T x = (T)(kmag_exact(g, i, j, l) * f.p[0]);
         T s, c;
         fb_sincos(x, &s, &c);

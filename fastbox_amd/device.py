@@ -285,6 +285,11 @@ class Engine(object):
         several concurrently running boxes its share) and 1 | 2 streams for alternate batches (0: by grid size)."""
         _lib.call("fb_set_plane_batching", self._plan, int(planes), int(streams))
 
+    def set_pass_schedule(self, plain=-1, generator=-1, binning=-1):
+        """0: one workgroup per tile; 1: resident workgroups walking the tiles; -1: the library's choice by grid size --
+        per class of strided FFT pass."""
+        _lib.call("fb_set_pass_schedule", self._plan, int(plain), int(generator), int(binning))
+
     def upload(self, arr, kind):
         """Host ndarray (N,N,N) -> device.  kind REAL or FULL."""
         N = self.N

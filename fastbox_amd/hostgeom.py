@@ -158,16 +158,16 @@ def shell_thresholds(N, Lside, bins):
 def finish_bins(cnt, s1, s2, boxfactor, eps=0.):
     """(mean, std/sqrt(n)) per bin from (count, sum |dk|^2, sum |dk|^4), bin 0 dropped (box.py:761-768); NaN for empty
     bins.  ``eps``: rounding unit of the |dk|^2 values the sums were formed from (2^-23 for a single-precision plan).
-    A bin that holds one mode and its mirror image (count 2: the same |dk|^2 twice for a real field) has exactly 0
-    spread in the reference's np.std; the form sum p^2 - (sum p)^2 / n leaves +-eps p^2 of rounding there instead,
-    whose square root would read as a spread of 2e-4 -- so for such a pair, and only there, a variance below
-    4 eps mean^2 is reported as 0.  Every other bin gets the variance its sums give (a spread below ~sqrt(eps) of the
+    A bin that holds one mode and its mirror image (count 2: the same |dk|^2 twice for a real field), or a single
+    self-mirrored mode (count 1: a corner of the grid), has exactly 0 spread in the reference's np.std; the form
+    sum p^2 - (sum p)^2 / n leaves +-eps p^2 of rounding there instead, whose square root would read as a spread of
+    2e-4 -- so for such bins, and only there, a variance below 4 eps mean^2 is reported as 0.  Every other bin gets the variance its sums give (a spread below ~sqrt(eps) of the
     mean is beyond what sums of single-precision squares resolve; the fp64 plan resolves 1e-8)."""
     with np.errstate(all="ignore"):
         vals = s1 / (cnt * boxfactor)
         var = (s2 - s1 * s1 / cnt) / cnt
         if eps:
-            var = np.where((cnt == 2) & (var <= 4. * eps * (s1 / cnt) ** 2), 0., var)
+            var = np.where((cnt <= 2) & (var <= 4. * eps * (s1 / cnt) ** 2), 0., var)
         stddev = np.sqrt(np.maximum(var, 0.)) / boxfactor / np.sqrt(cnt)
     return np.array(vals[1:]), np.array(stddev[1:])
 

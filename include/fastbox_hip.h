@@ -122,7 +122,8 @@ int fb_bin_power_filtered(fb_plan* plan, const void* spec, int layout, int kind,
  * ifftn(fftn(real_in) * T(k_perp, k_par)) for a real, k_par-even filter -- apply_transfer_fn followed by
  * binned_power_spectrum (box.py:356-381, :696-768).  r2c and y pass, then the x pass multiplies by T,
  * writes the FILTERED spectrum to filtered_half (fb_fft_c2r of it delivers the filtered field) and bins
- * it.  Asynchronous; results_dev as for fb_power_spectrum_device.                              */
+ * it.  kind: FB_FILT_TABLE, FB_FILT_BEAM_HIGHPASS or FB_FILT_WEDGE (FB_FILT_TOPHAT, smooth_field's window, is
+ * applied with fb_apply_filter: FB_ERR_UNSUPPORTED here).  Asynchronous; results_dev as for fb_power_spectrum_device. */
 int fb_power_spectrum_filtered(fb_plan* plan, const void* real_in, void* filtered_half, int kind,
                                const double* params, const void* table_dev, void* results_dev, void* stream);
 /* the same when what the caller goes on to read is the filtered FIELD (apply_transfer_fn's return value,
@@ -297,14 +298,16 @@ int fb_slab_x_generate(fb_plan* plan, void* kslab, int nparts, int part, uint64_
 /* results_dev[2*nbins]: this rank's (sum |dk|^2, sum |dk|^4) per bin; all-reduce (sum) over ranks */
 int fb_slab_x_bin(fb_plan* plan, void* kslab, int nparts, int part, double* results_dev, void* stream);
 
-/* start-up stagger of the second resident workgroup generation of the strided passes, in units of
- * 64 shader cycles, per pass kind (0 = off); see k_fft_strided */
-int fb_set_tuning(fb_plan* plan, int stagger_plain, int stagger_gen, int stagger_bin);
 /* The y and z passes of a transform run x-plane batch by x-plane batch so that a batch stays in the 256 MiB Infinity
  * Cache between them.  planes = -1: sized for ONE box using the GPU (default); when several boxes run concurrently on
  * their own streams, give each its share (e.g. 64 planes of a 512^3 box for two).  0 = whole box in one go.
  * streams = 2 sends alternate batches to a second stream of the plan; 0 = by grid size. */
 int fb_set_plane_batching(fb_plan* plan, int planes, int streams);
+/* How the strided FFT passes (x, y) of this plan are scheduled, per class (plain pass, fused generator pass, fused
+ * binning pass): 0 = one workgroup per tile, 1 = resident workgroups that walk the tiles and load their next tile
+ * while finishing the current one, -1 (default) = by grid size (resident where a CU holds one workgroup of the pass: N = 2048).  The transforms are bit-identical in both forms; the binning pass groups its fp64
+ * partial sums by resident workgroup instead of by tile (differences at the 1e-16 level).  Grids below 256^3 always use 0. */
+int fb_set_pass_schedule(fb_plan* plan, int plain, int generator, int binning);
 /* Fused log-normal transforms (pre_exp of fb_fft_r2c / fb_power_spectrum_device / _pending) form exp(x - shift).  The
  * estimate exp(d)/mean(exp(d)) - 1 does not depend on the shift (results[2 nbins] is the sum of the SHIFTED exponentials,
  * which is what the caller normalises with); the right shift keeps a single-precision plan's sum of exponentials (the
