@@ -62,6 +62,9 @@ def parse(argv=None):
                     help="replicas: every rank realises its own boxes (Monte-Carlo throughput, weak scaling; default). "
                          "slab: ONE box of --nsamp^3 spread over the ranks, slab-decomposed FFT with one RCCL "
                          "all-to-all per transform (strong scaling)")
+    ap.add_argument("--chunks", type=int, default=None,
+                    help="--mode slab: k_z chunks of ONE transform (the all-to-all of a chunk runs beside the passes of the "
+                         "next); default 4 with several ranks, 1 on one rank")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent realisations are issued round-robin on this many HIP streams (boxes)")
     ap.add_argument("--sizes", default="256,1024,2048", help="N = 1: other grid sizes of the `sizes` leg")
@@ -572,7 +575,7 @@ def main():
                 continue
             try:
                 rc, txt = spawn_ranks(world, ["--mode", "slab", "--nsamp", str(n2), "--steps", str(st), "--warmup", "2",
-                                              "--gpus", str(world), "--precision", args.precision], timeout=240)
+                                              "--gpus", str(world), "--precision", args.precision, "--chunks", "4"], timeout=240)
                 j = _last_json(txt)
                 out[str(n2)] = j if (rc == 0 and j) else {"error": "slab job rc=%s" % rc}
                 failed = not (rc == 0 and j)
@@ -594,8 +597,9 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
     from fastbox_amd.distributed import SlabBox
     N = args.nsamp
     torch.cuda.set_device(local_rank)
+    chunks = args.chunks if args.chunks is not None else (4 if world > 1 else 1)
     box = SlabBox(default_cosmo, box_scale=1e3, nsamp=N, precision=args.precision, seed=1000, rank=rank, world=world,
-                  device=local_rank)
+                  device=local_rank, chunks=chunks)
 
     def fence():
         torch.cuda.synchronize()
@@ -626,18 +630,21 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
         box.realise_and_power(nbins=args.nbins, lognormal=True)
     timed(3, False)
     dt = timed(args.steps, False)
-    dt_sync = timed(max(2, args.steps // 2), True) / max(2, args.steps // 2) if world > 1 else None
+    # one realisation at a time (BASELINE config 4: ONE box): with chunks > 1 each all-to-all runs beside the passes of
+    # the neighbouring chunks of the same transform; on one rank the figure is the cost of the chunked form itself
+    dt_sync = timed(max(2, args.steps // 2), True) / max(2, args.steps // 2) if (world > 1 or box.chunks > 1) else None
     if rank == 0:
         s = 4 if args.precision == "f32" else 8
         sweep = float(N) ** 3 * 2 * s
         a2a = (N // world) ** 2 * ((N // 2 + 16) // 16 * 16) * 2 * s
         timing = None if dt_sync is None else {
-            "ms_per_step_one_realisation_at_a_time": 1e3 * dt_sync,
+            "ms_per_step_one_realisation_at_a_time": 1e3 * dt_sync, "chunks_per_transform": box.chunks,
             "ms_per_step_pipelined": 1e3 * dt / args.steps,
             "all_to_alls_per_step": 2, "bytes_sent_per_rank_per_all_to_all": a2a * (world - 1),
             "note": "pipelined = up to three realisations in flight, both all-to-alls asynchronous on the RCCL stream "
-                    "behind other realisations' passes; the difference to the first figure is the exchange time that "
-                    "overlap hides"}
+                    "behind other realisations' passes (several ranks; on one rank it is the same loop as the first "
+                    "figure); one realisation at a time = every transform in `chunks_per_transform` k_z chunks, the "
+                    "all-to-all of a chunk beside the passes of the next"}
         print(json.dumps({
             "metric": "%d^3 box realisations/sec (gen + log-normal + P(k)), one box over all GPUs" % N,
             "value": args.steps / dt, "unit": "boxes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -90,6 +90,12 @@ SIGNATURES = {
     "fb_slab_x_pass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fb_slab_x_generate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_u64, c_u64, c_void_p]),
     "fb_slab_x_bin": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "fb_slab_tile_geometry": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "fb_slab_x_generate_chunk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_u64, c_u64, c_int, c_int, c_void_p]),
+    "fb_slab_y_inverse_chunk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "fb_slab_y_forward_chunk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "fb_slab_z_pass": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fb_slab_x_bin_chunk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fb_set_plane_batching": (c_int, [c_void_p, c_int, c_int]),
     "fb_set_pass_schedule": (c_int, [c_void_p, c_int, c_int, c_int]),
     "fb_set_exp_shift": (c_int, [c_void_p, ctypes.c_double]),

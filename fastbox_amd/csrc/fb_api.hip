@@ -628,6 +628,67 @@ int fb_slab_x_bin(fb_plan* p, void* kslab, int nparts, int part, double* results
     return FB_DISPATCH(p, fbi_slab_x_bin_f32(p, kslab, nyl, part * nyl, results_dev, s),
                        fbi_slab_x_bin_f64(p, kslab, nyl, part * nyl, results_dev, s));
 }
+// ---- chunked form: a range of k_z tile columns at a time (see fb_fft_launch.inc) ----
+int fb_slab_tile_geometry(const fb_plan* p, int* tile_columns, int* tiles_per_row) {
+    FB_REQUIRE(p && tile_columns && tiles_per_row, "null pointer");
+    const int tz = FB_DISPATCH(p, fbi_slab_tile_cols_f32(p), fbi_slab_tile_cols_f64(p));
+    *tile_columns = tz;
+    *tiles_per_row = (p->NZV + tz - 1) / tz;
+    return FB_OK;
+}
+static bool fb_chunk_ok(const fb_plan* p, int tile0, int ntile) {
+    const int tz = FB_DISPATCH(p, fbi_slab_tile_cols_f32(p), fbi_slab_tile_cols_f64(p));
+    return tile0 >= 0 && ntile > 0 && tile0 + ntile <= (p->NZV + tz - 1) / tz;
+}
+// (FB_SLAB_CHECK declares the device guard: it must stay in the function's own scope)
+#define FB_CHUNK_CHECK(p, nparts, tile0, ntile) \
+    FB_SLAB_CHECK(p, nparts);                   \
+    FB_REQUIRE(fb_chunk_ok(p, tile0, ntile), "tile range outside the half spectrum")
+int fb_slab_x_generate_chunk(fb_plan* p, void* kchunk, int nparts, int part, uint64_t seed, uint64_t realisation, int tile0,
+                             int ntile, void* stream) {
+    FB_CHUNK_CHECK(p, nparts, tile0, ntile);
+    FB_REQUIRE(kchunk && part >= 0 && part < nparts, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nyl = p->N / nparts;
+    return FB_DISPATCH(p, fbi_slab_x_generate_chunk_f32(p, kchunk, nyl, part * nyl, seed, realisation, tile0, ntile, s),
+                       fbi_slab_x_generate_chunk_f64(p, kchunk, nyl, part * nyl, seed, realisation, tile0, ntile, s));
+}
+int fb_slab_y_inverse_chunk(fb_plan* p, const void* recv_chunk, void* half_local, int nparts, int tile0, int ntile, void* stream) {
+    FB_CHUNK_CHECK(p, nparts, tile0, ntile);
+    FB_REQUIRE(recv_chunk && half_local && recv_chunk != half_local, "bad buffers");
+    hipStream_t s = (hipStream_t)stream;
+    const int nxl = p->N / nparts;
+    return FB_DISPATCH(p, fbi_slab_y_inverse_chunk_f32(p, recv_chunk, half_local, nxl, nparts, tile0, ntile, s),
+                       fbi_slab_y_inverse_chunk_f64(p, recv_chunk, half_local, nxl, nparts, tile0, ntile, s));
+}
+int fb_slab_y_forward_chunk(fb_plan* p, const void* half_local, void* send_chunk, int nparts, int tile0, int ntile, void* stream) {
+    FB_CHUNK_CHECK(p, nparts, tile0, ntile);
+    FB_REQUIRE(send_chunk && half_local && send_chunk != half_local, "bad buffers");
+    hipStream_t s = (hipStream_t)stream;
+    const int nxl = p->N / nparts;
+    return FB_DISPATCH(p, fbi_slab_y_forward_chunk_f32(p, half_local, send_chunk, nxl, nparts, tile0, ntile, s),
+                       fbi_slab_y_forward_chunk_f64(p, half_local, send_chunk, nxl, nparts, tile0, ntile, s));
+}
+int fb_slab_z_pass(fb_plan* p, void* half_local, void* real_local, int nparts, int which, int pre_exp, double* expsum_dev,
+                   void* stream) {
+    FB_SLAB_CHECK(p, nparts);
+    FB_REQUIRE(half_local && (real_local || which == 2) && which >= 0 && which <= 2, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nxl = p->N / nparts;
+    const double scale = 1.0 / ((double)p->N * p->N * p->N);
+    return FB_DISPATCH(p, fbi_slab_z_pass_f32(p, half_local, real_local, nxl, which, scale, pre_exp, expsum_dev, s),
+                       fbi_slab_z_pass_f64(p, half_local, real_local, nxl, which, scale, pre_exp, expsum_dev, s));
+}
+int fb_slab_x_bin_chunk(fb_plan* p, void* kchunk, int nparts, int part, int tile0, int ntile, int first, int last,
+                        double* results_dev, void* stream) {
+    FB_CHUNK_CHECK(p, nparts, tile0, ntile);
+    FB_REQUIRE(kchunk && part >= 0 && part < nparts && (results_dev || !last), "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nyl = p->N / nparts;
+    return FB_DISPATCH(p, fbi_slab_x_bin_chunk_f32(p, kchunk, nyl, part * nyl, tile0, ntile, first, last, results_dev, s),
+                       fbi_slab_x_bin_chunk_f64(p, kchunk, nyl, part * nyl, tile0, ntile, first, last, results_dev, s));
+}
+
 int64_t fb_slab_half_bytes(const fb_plan* p, int nparts) {
     return (p && nparts > 0) ? (int64_t)(p->N / nparts) * p->NR * p->NZP * 2 * p->prec : 0;
 }

@@ -80,6 +80,13 @@ template <typename T> struct StridedArgs {
     long long blk_stride;
     int blk_in, blk_out, blk_shift;
     int packed;              // half spectrum with the k_z = N/2 plane in the imaginary direction of the k_z = 0 plane (ncols = N/2)
+    // A launch over a RANGE of tile columns (the k_z chunks of the slab-decomposed transform, whose all-to-all of one
+    // chunk runs beside the passes of the next): tiles tile0 .. tile0 + ntx - 1 of a row.  Columns stay absolute
+    // (ncols, the generator's counters, the binning's k_z), so a chunk that lives in an array of its own is handed
+    // over as  base - (first column of the chunk).
+    int tile0;
+    long long out_stride;    // slab addressing only: elements between consecutive points of a line on the OUTPUT side when that
+                             // differs from `stride` (a chunk array has its own row pitch); 0 = as `stride`
 };
 
 // operands of the fused modes (x pass of a half spectrum: line index = k_x,
@@ -178,16 +185,21 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     const unsigned estep_b = (unsigned)(estep * (long long)sizeof(cx<T>));       // meaningful when !a.wide
     // offset of a thread's e-th point in the slab addressing (e is a compile-time constant after unrolling, the rest is
     // wave-uniform)
-    [[maybe_unused]] auto eoff = [&](int e, int blocked) -> long long {
-        return blocked ? (long long)(e >> a.blk_shift) * a.blk_stride + (long long)(e & ((1 << a.blk_shift) - 1)) * estep
-                       : (long long)e * estep;
+    [[maybe_unused]] auto eoff = [&](int e, int blocked, long long es) -> long long {
+        return blocked ? (long long)(e >> a.blk_shift) * a.blk_stride + (long long)(e & ((1 << a.blk_shift) - 1)) * es
+                       : (long long)e * es;
     };
+    // output side of the slab addressing: its own row pitch when the two sides differ (chunk arrays)
+    [[maybe_unused]] const long long ostride = (BLK && a.out_stride) ? a.out_stride : a.stride;
+    [[maybe_unused]] const long long tbase_o = BLK ? (long long)t0 * ostride : tbase;
+    [[maybe_unused]] const unsigned loff_o = BLK ? (unsigned)(((long long)(t - t0) * ostride + c) * (long long)sizeof(cx<T>)) : loff;
+    [[maybe_unused]] const long long estep_o = BLK ? (long long)TPL * ostride : estep;
     // the E points of this thread from / to the tile whose first row (this wave's) starts at src / dst
     auto load_rows = [&](cx<T> (&r)[E], const cx<T>* src, const unsigned voff) {
         constexpr int AUX = smode_bins(MODE) ? FB_BIN_LOAD_AUX : 0;
         if constexpr (BLK) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) r[e] = buf_load<AUX>(make_rsrc(src + eoff(e, a.blk_in)), voff, 0u, src);
+            for (int e = 0; e < E; ++e) r[e] = buf_load<AUX>(make_rsrc(src + eoff(e, a.blk_in, estep)), voff, 0u, src);
         } else if (!a.wide) {
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(src);
 #pragma unroll
@@ -201,7 +213,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         constexpr int AUX = MODE == SMODE_GEN ? FB_GEN_STORE_AUX : 0;
         if constexpr (BLK) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) buf_store<AUX>(make_rsrc(dst + eoff(e, a.blk_out)), voff, 0u, cscale(r[e], scale));
+            for (int e = 0; e < E; ++e) buf_store<AUX>(make_rsrc(dst + eoff(e, a.blk_out, estep_o)), voff, 0u, cscale(r[e], scale));
         } else if (!a.wide) {
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(dst);
 #pragma unroll
@@ -268,6 +280,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             if (bx - lg + G <= a.ntx) bx = (bx - lg) + LPT * (lg % 8) + lg / 8;
         }
 #endif
+        bx += a.tile0;            // (0 unless the launch covers a range of tile columns)
     };
     int tile_id = blockIdx.x;
     // loads of tile `id` into v[] (ids past the last tile: every lane gets the out-of-range offset, which the buffer
@@ -549,8 +562,8 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             if (op.store == 2) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, layf);
         }
         if constexpr (!smode_bins(MODE) || MODE == SMODE_BINF) {
-            cx<T>* dst = a.out + ((long long)by * out_outer + bx * TZ) + tbase;
-            const unsigned voff = (valid && !a.drop_io) ? loff : FB_BUF_OOB;
+            cx<T>* dst = a.out + ((long long)by * out_outer + bx * TZ) + tbase_o;
+            const unsigned voff = (valid && !a.drop_io) ? loff_o : FB_BUF_OOB;
             store_rows(dst, voff, v, a.scale);
             // resident workgroup, plain pass: the next tile's loads go out right behind the stores (a store has read its
             // registers when it issues), so its memory latency runs beside this tile's store drain
@@ -733,10 +746,11 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 // the log-normal mean's block sums ride along with the bin sums in one launch)
 static __global__ __launch_bounds__(1024) void k_sum_columns(const double* __restrict__ partial, long long nrows,
                                                               int nvals, double* __restrict__ out,
-                                                              const double* __restrict__ partial2, long long nrows2) {
+                                                              const double* __restrict__ partial2, long long nrows2,
+                                                              long long stride = 0) {      // rows a value's partials are apart (0: nrows)
     __shared__ double sh[1024];
     const int q = blockIdx.x, nt = blockDim.x;       // nt: a power of two, 64 .. 1024
-    const double* src = partial + (size_t)q * nrows;
+    const double* src = partial + (size_t)q * (stride ? stride : nrows);
     if (q == nvals) {
         if (!partial2) { if (threadIdx.x == 0) out[q] = 0.0; return; }
         src = partial2; nrows = nrows2;

@@ -61,6 +61,7 @@ struct fb_plan {
     size_t bin_partials_cap = 0;
     long long bin_rows = 0;
     long long bin_rows_main = 0;      // of which the fused binning pass itself wrote (the rest: k_bin_packed_plane)
+    long long bin_append_cap = 0;     // > 0: binning launches append their columns to a shared table of this many (k_z chunks)
     void* plane_buf = nullptr;        // packed work spectra: the shared plane column after the last forward pass, [N][N] complex
     double* exp_partials = nullptr;   // r2c with exp(): [workgroups]
     size_t exp_partials_cap = 0;
@@ -181,7 +182,18 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_slab_inverse_local_##sfx(fb_plan* p, void* half_local, void* real_local, int nxl, double scale, hipStream_t s); \
     int fbi_slab_x_pass_##sfx(fb_plan* p, void* kslab, int nyl, int sign, hipStream_t s); \
     int fbi_slab_x_generate_##sfx(fb_plan* p, void* kslab, int nyl, int ky0, uint64_t seed, uint64_t real, hipStream_t s); \
-    int fbi_slab_x_bin_##sfx(fb_plan* p, void* kslab, int nyl, int ky0, double* results, hipStream_t s);
+    int fbi_slab_x_bin_##sfx(fb_plan* p, void* kslab, int nyl, int ky0, double* results, hipStream_t s); \
+    int fbi_slab_tile_cols_##sfx(const fb_plan* p); \
+    int fbi_slab_x_generate_chunk_##sfx(fb_plan* p, void* kchunk, int nyl, int ky0, uint64_t seed, uint64_t real, int tile0, \
+                                        int ntile, hipStream_t s); \
+    int fbi_slab_y_inverse_chunk_##sfx(fb_plan* p, const void* recv_chunk, void* half_local, int nxl, int nparts, int tile0, \
+                                       int ntile, hipStream_t s); \
+    int fbi_slab_y_forward_chunk_##sfx(fb_plan* p, const void* half_local, void* send_chunk, int nxl, int nparts, int tile0, \
+                                       int ntile, hipStream_t s); \
+    int fbi_slab_z_pass_##sfx(fb_plan* p, void* half_local, void* real_local, int nxl, int which, double scale, int pre_exp, \
+                              double* expsum, hipStream_t s); \
+    int fbi_slab_x_bin_chunk_##sfx(fb_plan* p, void* kchunk, int nyl, int ky0, int tile0, int ntile, int first, int last, \
+                                   double* results, hipStream_t s);
 FB_DECL(f32)
 FB_DECL(f64)
 int fbi_bin_count(fb_plan* p, hipStream_t s);

@@ -21,7 +21,16 @@ Each ordered pair of ranks exchanges (N/P)(N/P)(pitch) complex values; with P = 
 a GPU carry one peer each.  The device noise depends on global mode indices only, so the field is
 identical for every P (tests compare P = 1, 2, 4).
 
-Communication / compute overlap: a Monte-Carlo loop has independent realisations, so the exchanges of one are
+Communication / compute overlap, two forms.  (1) Inside ONE transform (``SlabBox(..., chunks=C)``; BASELINE config 4
+is a single box): the x and y passes never mix k_z columns, so the half spectrum is cut into C chunks of k_z tile
+columns, each chunk of the k-slab / exchange buffers an array of its own (equal contiguous blocks per rank), and
+
+  compute stream :  GEN-x(0) GEN-x(1) GEN-x(2) ...  y(0) y(1) ...  z (whole rows)  y(0) y(1) ...   BIN-x(0) BIN-x(1) ...
+  RCCL stream    :      a2a(0)   a2a(1)   a2a(2) ...                                  a2a(0) a2a(1) ...
+
+the all-to-all of chunk c runs while the passes of the chunks after it (and the y passes of those before it) are
+computed; only the z pass, which needs whole rows, has nothing beside it.  Fields are bit-identical for every C.
+(2) Across realisations: a Monte-Carlo loop has independent realisations, so the exchanges of one are
 hidden behind the passes of its neighbours -- ``realise_and_power(wait=False)`` keeps up to three realisations in
 flight on this rank,
 
@@ -31,8 +40,7 @@ flight on this rank,
 (GEN = generator + x pass of the k-slab, x1 = its all-to-all, turn = y pass, fused z passes, y pass of the x-slab,
 x2 = the all-to-all back, BIN = x pass with the shell binning): both all-to-alls of a realisation run as asynchronous
 collectives while the compute stream works on another realisation, with three rotating buffer pairs.  The kernels are
-those of the synchronous path, the fields are bit-identical, and -- unlike a chunked exchange inside one transform,
-which cannot start before the first pass has produced every destination's block -- the FIRST exchange is hidden too.
+those of the synchronous path, the fields are bit-identical, and the z pass is covered as well.
 Bin sums stay on the device (a ring of records, all-reduced asynchronously) until ``result()`` is called.
 
 The per-rank arithmetic is behind a small "ops" interface: ``HipSlabOps`` drives libfastbox_hip (no
@@ -130,6 +138,38 @@ class HipSlabOps(object):
     def pack(self, half_local, send):
         self._call("fb_slab_pack", half_local.data_ptr(), send.data_ptr(), self.P, self._stream())
 
+    # the same passes over a range of k_z tile columns (a chunk lives in an array of its own, see fastbox_hip.h)
+    def tile_geometry(self):
+        """(k_z columns per tile of the strided passes, tiles per row of the half spectrum)"""
+        tz, nt = ctypes.c_int(), ctypes.c_int()
+        self._call("fb_slab_tile_geometry", ctypes.byref(tz), ctypes.byref(nt))
+        return tz.value, nt.value
+
+    def new_chunk_store(self, total_columns):
+        """flat buffer for the chunk arrays of one exchange side: [N][N/P][total_columns] complex in all"""
+        return self.torch.empty((self.N * self.nloc * total_columns * 2,), dtype=self.rdtype, device=self.dev)
+
+    def x_generate_chunk(self, kchunk, seed, realisation, tile0, ntile):
+        self._call("fb_slab_x_generate_chunk", kchunk.data_ptr(), self.P, self.part, seed & (2 ** 64 - 1),
+                   realisation & (2 ** 64 - 1), tile0, ntile, self._stream())
+
+    def y_inverse_chunk(self, recv_chunk, half_local, tile0, ntile):
+        self._call("fb_slab_y_inverse_chunk", recv_chunk.data_ptr(), half_local.data_ptr(), self.P, tile0, ntile,
+                   self._stream())
+
+    def y_forward_chunk(self, half_local, send_chunk, tile0, ntile):
+        self._call("fb_slab_y_forward_chunk", half_local.data_ptr(), send_chunk.data_ptr(), self.P, tile0, ntile,
+                   self._stream())
+
+    def z_pass(self, half_local, real, which, pre_exp=False, expsum=None):
+        """which: 0 half -> real, 1 real -> half (of exp(real) if pre_exp), 2 half -> real -> half of (exp of) it"""
+        self._call("fb_slab_z_pass", half_local.data_ptr(), real.data_ptr(), self.P, which, 1 if pre_exp else 0,
+                   expsum.data_ptr() if (pre_exp and expsum is not None) else None, self._stream())
+
+    def x_bin_chunk(self, kchunk, tile0, ntile, first, last, results):
+        self._call("fb_slab_x_bin_chunk", kchunk.data_ptr(), self.P, self.part, tile0, ntile, 1 if first else 0,
+                   1 if last else 0, results.data_ptr(), self._stream())
+
     def x_bin(self, kslab, results):
         self._call("fb_slab_x_bin", kslab.data_ptr(), self.P, self.part, results.data_ptr(), self._stream())
 
@@ -139,7 +179,7 @@ class SlabBox(object):
     for cubic boxes with the device RNG.  Collective: every rank of the group calls each method."""
 
     def __init__(self, cosmo, box_scale=1e3, nsamp=512, redshift=0., precision="f32", seed=0,
-                 rank=None, world=None, group=None, ops_factory=None, device=None, pk_fn=None):
+                 rank=None, world=None, group=None, ops_factory=None, device=None, pk_fn=None, chunks=1):
         import torch.distributed as dist
         self._dist = dist
         self.group = group
@@ -190,6 +230,19 @@ class SlabBox(object):
         self._ring, self._ring_next = None, 0
         self._inflight, self._retired = [], []     # _Ticket objects, oldest first
         self._submitted = 0                        # tickets handed out so far: ticket i owns buffer pair i % 3
+        # ONE transform in `chunks` pieces along k_z (the x and y passes never mix k_z columns): the all-to-all of a
+        # chunk runs while the passes of the next are computed -- what hides the exchange of a single box (BASELINE
+        # config 4), where there is no neighbouring realisation to hide it behind
+        self.chunks = 1
+        self._chunk_tab = None
+        if hasattr(self.ops, "tile_geometry"):
+            tz, ntile = self.ops.tile_geometry()
+            C = max(1, min(int(chunks or 1), ntile))
+            sizes = [ntile // C + (1 if i < ntile % C else 0) for i in range(C)]
+            starts = [sum(sizes[:i]) for i in range(C)]
+            self.chunks, self._chunk_tab, self._chunk_tz = C, list(zip(starts, sizes)), tz
+            self._chunk_cols = ntile * tz
+            self._cstore = [None, None]            # the two exchange sides, as chunk arrays (allocated on first use)
 
     def _fused(self, call):
         """Run the exchange-buffer-addressing form of a y pass if the backend has it and the rank count allows it
@@ -247,9 +300,63 @@ class SlabBox(object):
         self.delta_x = real
         return real
 
+    # -- one transform in k_z chunks (self.chunks > 1) ---------------------------------------------
+    def _chunk_views(self, side):
+        """The chunk arrays [N][N/P][W_c] (x 2 reals) of exchange side 0 / 1: views into one flat allocation."""
+        if self._cstore[side] is None:
+            flat = self.ops.new_chunk_store(self._chunk_cols)
+            views, off = [], 0
+            for t0, nt in self._chunk_tab:
+                n = self.N * (self.N // self.world) * nt * self._chunk_tz * 2
+                views.append(flat[off:off + n])
+                off += n
+            self._cstore[side] = (flat, views)
+        return self._cstore[side][1]
+
+    def _exchange_chunk(self, send, recv):
+        """Start the all-to-all of one chunk array; returns (handle or None, buffer that will hold the result)."""
+        if self.world == 1:
+            return None, send
+        return self._exchange_async(send, recv), recv
+
+    def _inverse_chunked(self):
+        """generator + x pass, exchange, y pass -- chunk by chunk; leaves the x-slab's half spectrum in self._half"""
+        A, B = self._chunk_views(0), self._chunk_views(1)
+        moves = []
+        for c, (t0, nt) in enumerate(self._chunk_tab):
+            self.ops.x_generate_chunk(A[c], self.seed, self._realisation, t0, nt)
+            moves.append(self._exchange_chunk(A[c], B[c]))          # runs beside the generator pass of chunk c + 1
+        self._realisation += 1
+        for c, (t0, nt) in enumerate(self._chunk_tab):
+            w, buf = moves[c]
+            if w is not None:
+                w.wait()
+            self.ops.y_inverse_chunk(buf, self._half, t0, nt)       # ... and beside the y passes of the chunks before
+
+    def _forward_chunked(self, nb):
+        """y pass, exchange, x pass with the binning -- chunk by chunk, from self._half; returns the bin sums"""
+        A, B = self._chunk_views(0), self._chunk_views(1)
+        moves = []
+        for c, (t0, nt) in enumerate(self._chunk_tab):
+            self.ops.y_forward_chunk(self._half, A[c], t0, nt)
+            moves.append(self._exchange_chunk(A[c], B[c]))
+        last = len(self._chunk_tab) - 1
+        for c, (t0, nt) in enumerate(self._chunk_tab):
+            w, buf = moves[c]
+            if w is not None:
+                w.wait()
+            self.ops.x_bin_chunk(buf, t0, nt, c == 0, c == last, self._res)
+        return self._res
+
     def realise_density(self):
         """This rank's x-slab of delta_x (kept in ``self.delta_x``)."""
         self._drain()          # tickets in flight read / write the buffers this call is about to use
+        if self.chunks > 1:
+            self._inverse_chunked()
+            real = self.ops.new_real()
+            self.ops.z_pass(self._half, real, 0)
+            self.delta_x = real
+            return real
         send = self._gen_local()
         return self._gen_finish(self._exchange(send, self._xbuf))
 
@@ -301,6 +408,18 @@ class SlabBox(object):
         nb = bins.size
         if lognormal and not bins[0] > 0.:
             raise ValueError("the fused log-normal P(k) needs kbins[0] > 0")
+        if self.chunks > 1:
+            self._inverse_chunked()
+            self._res = self.ops.new_results(2 * nb + 1)
+            real = self.ops.new_real()
+            self.ops.z_pass(self._half, real, 2, lognormal, self._res[2 * nb:])     # delta_x written once, not read back
+            self.delta_x = real
+            res = self._forward_chunked(nb)
+            idx = self._realisation - 1
+            redo = lambda: self._redo_lognormal(None, nbins, kbins, realisation=idx)
+            if not wait:
+                return _Deferred(self, res, kc, nb, lognormal, redo)
+            return self._finish_power(res, kc, nb, lognormal, redo)
         recv = self._exchange(self._gen_local(), self._xbuf)
         self._res = self.ops.new_results(2 * nb + 1)
         real = self.ops.new_real()
@@ -446,9 +565,17 @@ class SlabBox(object):
         nb = bins.size
         if lognormal and not bins[0] > 0.:
             raise ValueError("the fused log-normal P(k) needs kbins[0] > 0")
-        send = self._pk_local(real, lognormal, nb)
-        res = self._pk_finish(self._exchange(send, self._kslab), nb)
+        res = self._pk_of(real, lognormal, nb)
         return self._finish_power(res, kc, nb, lognormal, redo=lambda: self._redo_lognormal(real, nbins, kbins))
+
+    def _pk_of(self, real, lognormal, nb):
+        """bin sums (not yet all-reduced) of the distributed field `real` (of exp of it if `lognormal`)"""
+        if self.chunks > 1:
+            self._res = self.ops.new_results(2 * nb + 1)
+            self.ops.z_pass(self._half, real, 1, lognormal, self._res[2 * nb:])
+            return self._forward_chunked(nb)
+        send = self._pk_local(real, lognormal, nb)
+        return self._pk_finish(self._exchange(send, self._kslab), nb)
 
     def _redo_lognormal(self, real, nbins, kbins, realisation=None):
         """Bin sums of the log-normal transform of `real` (or of realisation number `realisation`, drawn again) with
@@ -470,8 +597,7 @@ class SlabBox(object):
         try:
             bins, kc = self._pk_setup(nbins, kbins)
             nb = bins.size
-            send = self._pk_local(real, True, nb)
-            res = self._pk_finish(self._exchange(send, self._kslab), nb)
+            res = self._pk_of(real, True, nb)
             self._all_reduce(res)
             h = res.detach().cpu().numpy()
         finally:
@@ -529,3 +655,40 @@ def run_virtual(boxes, fn_local, fn_finish):
             flat[q].copy_(sends[q].view(P, -1)[r])
         recvs.append(recv)
     return [fn_finish(b, recv) for b, recv in zip(boxes, recvs)]
+
+
+def run_virtual_chunked(boxes, nb, lognormal):
+    """The chunked ``realise_and_power`` of several SlabBox objects that live in ONE process (virtual ranks on a single
+    GPU): every chunk's all-to-all is done by block copies.  Leaves each box's x-slab in ``delta_x`` and returns the
+    per-rank bin-sum records (to be added up, as the all-reduce would)."""
+    P = len(boxes)
+    tab = boxes[0]._chunk_tab
+    A = [b._chunk_views(0) for b in boxes]
+    B = [b._chunk_views(1) for b in boxes]
+
+    def exchange(c):
+        for r in range(P):
+            dst = B[r][c].view(P, -1)
+            for q in range(P):
+                dst[q].copy_(A[q][c].view(P, -1)[r])
+    for b, a in zip(boxes, A):
+        for c, (t0, nt) in enumerate(tab):
+            b.ops.x_generate_chunk(a[c], b.seed, b._realisation, t0, nt)
+        b._realisation += 1
+    for c in range(len(tab)):
+        exchange(c)
+    for b, bb in zip(boxes, B):
+        for c, (t0, nt) in enumerate(tab):
+            b.ops.y_inverse_chunk(bb[c], b._half, t0, nt)
+        b._res = b.ops.new_results(2 * nb + 1)
+        b.delta_x = b.ops.new_real()
+        b.ops.z_pass(b._half, b.delta_x, 2, lognormal, b._res[2 * nb:])
+        for c, (t0, nt) in enumerate(tab):
+            b.ops.y_forward_chunk(b._half, A[boxes.index(b)][c], t0, nt)
+    for c in range(len(tab)):
+        exchange(c)
+    last = len(tab) - 1
+    for b, bb in zip(boxes, B):
+        for c, (t0, nt) in enumerate(tab):
+            b.ops.x_bin_chunk(bb[c], t0, nt, c == 0, c == last, b._res)
+    return [b._res for b in boxes]

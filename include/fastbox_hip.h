@@ -298,6 +298,35 @@ int fb_slab_x_generate(fb_plan* plan, void* kslab, int nparts, int part, uint64_
 /* results_dev[2*nbins]: this rank's (sum |dk|^2, sum |dk|^4) per bin; all-reduce (sum) over ranks */
 int fb_slab_x_bin(fb_plan* plan, void* kslab, int nparts, int part, double* results_dev, void* stream);
 
+/* ---- the same transform a range of k_z columns at a time, so that the all-to-all of one chunk of the half spectrum runs
+ * beside the passes of the next (the x and y passes never mix k_z columns; only the z pass needs whole rows).
+ * The strided passes work on tiles of `tile_columns` adjacent k_z columns; a row of the half spectrum has `tiles_per_row`
+ * of them (fb_slab_tile_geometry); a chunk is the tile range [tile0, tile0 + ntile).  A chunk of the k-space slab and of
+ * an exchange buffer is an ARRAY OF ITS OWN with row pitch W = ntile * tile_columns:
+ *     k-chunk        complex[N][N/nparts][W]                 (x-major; block q = x-planes of rank q: contiguous)
+ *     exchange chunk complex[nparts][N/nparts][N/nparts][W]  ([rank][x][k_y in rank][k_z in chunk])
+ * -- equal contiguous blocks per rank, which is what the collective moves.  The x-slab's half spectrum `half_local`
+ * ([N/nparts][N+1][pitch]) keeps all columns in one array.
+ *   realise_density : fb_slab_x_generate_chunk(c) -> all-to-all(c) -> fb_slab_y_inverse_chunk(c), all c; fb_slab_z_pass(0)
+ *   P(k)            : fb_slab_z_pass(1) -> fb_slab_y_forward_chunk(c) -> all-to-all(c) -> fb_slab_x_bin_chunk(c), all c
+ *   both in one     : ... fb_slab_y_inverse_chunk(c) all c; fb_slab_z_pass(2); fb_slab_y_forward_chunk(c) ...
+ * Fields are bit-identical to the unchunked calls for any chunking.                                                  */
+int fb_slab_tile_geometry(const fb_plan* plan, int* tile_columns, int* tiles_per_row);
+int fb_slab_x_generate_chunk(fb_plan* plan, void* kchunk, int nparts, int part, uint64_t seed, uint64_t realisation,
+                             int tile0, int ntile, void* stream);
+int fb_slab_y_inverse_chunk(fb_plan* plan, const void* recv_chunk, void* half_local, int nparts, int tile0, int ntile,
+                            void* stream);
+int fb_slab_y_forward_chunk(fb_plan* plan, const void* half_local, void* send_chunk, int nparts, int tile0, int ntile,
+                            void* stream);
+/* which: 0 = half_local -> real_local (c2r, numpy's 1/N^3), 1 = real_local -> half_local (r2c; of exp(real - shift) when
+ * pre_exp, expsum_dev[0] = this rank's sum of them), 2 = c2r, store the field, r2c of (exp of) it from registers        */
+int fb_slab_z_pass(fb_plan* plan, void* half_local, void* real_local, int nparts, int which, int pre_exp,
+                   double* expsum_dev, void* stream);
+/* first / last: the first and the last chunk of a spectrum (any order in between); results_dev as fb_slab_x_bin, written by
+ * the last call */
+int fb_slab_x_bin_chunk(fb_plan* plan, void* kchunk, int nparts, int part, int tile0, int ntile, int first, int last,
+                        double* results_dev, void* stream);
+
 /* The y and z passes of a transform run x-plane batch by x-plane batch so that a batch stays in the 256 MiB Infinity
  * Cache between them.  planes = -1: sized for ONE box using the GPU (default); when several boxes run concurrently on
  * their own streams, give each its share (e.g. 64 planes of a 512^3 box for two).  0 = whole box in one go.

@@ -93,3 +93,59 @@ class NumpySlabOps(object):
         out = results.numpy()
         out[0:2 * nb:2] = np.bincount(idx, weights=wp, minlength=nb + 1)[:nb]
         out[1:2 * nb:2] = np.bincount(idx, weights=wp2, minlength=nb + 1)[:nb]
+
+    # ---- the chunked interface (a range of k_z tile columns at a time; a chunk is an array of its own) ----
+    TZ = 2                       # columns per tile of this test double (the HIP kernels use 16 / 8 / 4 / 2)
+
+    def tile_geometry(self):
+        return self.TZ, (self.nz + self.TZ - 1) // self.TZ
+
+    def new_chunk_store(self, total_columns):
+        return torch.zeros((self.N * self.nloc * total_columns * 2,), dtype=torch.float64)
+
+    def _chunk(self, t, lead, tile0, ntile):
+        """complex view [lead...][W] of a flat chunk array, its first absolute column, and how many of its columns exist"""
+        W = ntile * self.TZ
+        a = t.numpy().view(np.complex128).reshape(lead + (W,))
+        col0 = tile0 * self.TZ
+        return a, col0, max(0, min(W, self.nz - col0))
+
+    def x_generate_chunk(self, kchunk, seed, realisation, tile0, ntile):
+        a, col0, nv = self._chunk(kchunk, (self.N, self.nloc), tile0, ntile)
+        z = rng.half_spectrum_noise(self.N, seed, realisation)[:, self.part * self.nloc:(self.part + 1) * self.nloc, :]
+        H = z * self.amp[self._n2()]
+        a[:, :, :nv] = np.fft.ifft(H, axis=0)[:, :, col0:col0 + nv]
+
+    def y_inverse_chunk(self, recv_chunk, half_local, tile0, ntile):
+        # (layout only: this double takes the y transform together with the z transform, in z_pass)
+        r, col0, nv = self._chunk(recv_chunk, (self.P, self.nloc, self.nloc), tile0, ntile)
+        h = self._c(half_local)
+        for q in range(self.P):
+            h[:, q * self.nloc:(q + 1) * self.nloc, col0:col0 + nv] = r[q][:, :, :nv]
+
+    def y_forward_chunk(self, half_local, send_chunk, tile0, ntile):
+        sd, col0, nv = self._chunk(send_chunk, (self.P, self.nloc, self.nloc), tile0, ntile)
+        h = self._c(half_local)
+        for q in range(self.P):
+            sd[q][:, :, :nv] = h[:, q * self.nloc:(q + 1) * self.nloc, col0:col0 + nv]
+
+    def z_pass(self, half_local, real, which, pre_exp=False, expsum=None):
+        if which in (0, 2):
+            self.inverse_local(half_local, real)
+        if which in (1, 2):
+            self.forward_local(real, half_local, pre_exp, expsum)
+
+    def x_bin_chunk(self, kchunk, tile0, ntile, first, last, results):
+        a, col0, nv = self._chunk(kchunk, (self.N, self.nloc), tile0, ntile)
+        nb = self.bins.size
+        X = np.fft.fft(a[:, :, :nv], axis=0)
+        p = np.abs(X) ** 2
+        k = 2. * np.pi * np.sqrt(self._n2()[:, :, col0:col0 + nv].astype(np.float64)) / self.g["L"][0]
+        idx = np.digitize(k.ravel(), self.bins)
+        w = np.full(self.nz, 2.0); w[0] = w[-1] = 1.0
+        w = w[col0:col0 + nv]
+        out = results.numpy()
+        if first:
+            out[0:2 * nb] = 0.0
+        out[0:2 * nb:2] += np.bincount(idx, weights=(p * w[None, None, :]).ravel(), minlength=nb + 1)[:nb]
+        out[1:2 * nb:2] += np.bincount(idx, weights=(p * p * w[None, None, :]).ravel(), minlength=nb + 1)[:nb]

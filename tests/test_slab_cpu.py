@@ -188,6 +188,61 @@ def test_out_of_range_lognormal_step_is_repeated_with_the_exact_shift(tmp_path):
         assert np.allclose(g["want"], g["got"], rtol=1e-9, atol=0, equal_nan=True)
 
 
+def _chunk_worker(rank, world, port, out_dir):
+    """One transform in C chunks along k_z (the all-to-all of a chunk runs beside the passes of the next): every
+    call form, C = 1, 2, 4 (5 tiles: uneven chunks), against the unchunked box."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fastbox_amd.distributed import SlabBox
+        from tests.slab_numpy_ops import NumpySlabOps
+        mk = lambda C: SlabBox(standin.DEFAULT_COSMO, box_scale=L, nsamp=N, seed=SEED, rank=rank, world=world,
+                               ops_factory=lambda g, P, r: NumpySlabOps(g, P, r),
+                               pk_fn=standin.pk_fn(standin.cosmology(), 1.0), chunks=C)
+        out = {}
+        for C in (1, 2, 4):
+            b = mk(C)
+            assert b.chunks == C
+            dx0 = b.realise_density().numpy().copy()
+            pk0 = b.binned_power_spectrum(nbins=12)
+            ln0 = b.binned_power_spectrum(nbins=12, lognormal=True)
+            rp = [b.realise_and_power(nbins=12, lognormal=(i == 1)) for i in range(2)]
+            dx2 = b.delta_x.numpy().copy()
+            d = b.realise_and_power(nbins=12, wait=False).result()
+            out["dx0_%d" % C], out["dx2_%d" % C] = dx0, dx2
+            out["pk_%d" % C] = np.array([pk0, ln0] + rp + [d])
+        np.savez(os.path.join(out_dir, "ch%d_%d.npz" % (world, rank)), **out)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_chunked_transform_equals_unchunked(tmp_path, world):
+    if world == 1:
+        _chunk_worker(0, 1, _free_port(), str(tmp_path))
+    else:
+        mp.spawn(_chunk_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(os.path.join(str(tmp_path), "ch%d_%d.npz" % (world, r))) for r in range(world)]
+    want_dx, want_pk, want_ln = _expected()
+    full = np.concatenate([g["dx0_1"] for g in got], axis=0)
+    assert np.max(np.abs(full - want_dx)) < 1e-12 * np.std(want_dx)                 # the unchunked box against the oracle
+    for g in got:
+        for C in (2, 4):
+            assert np.array_equal(g["dx0_%d" % C], g["dx0_1"]) and np.array_equal(g["dx2_%d" % C], g["dx2_1"])   # fields: bit for bit
+            assert np.allclose(g["pk_%d" % C], g["pk_1"], rtol=1e-12, atol=0, equal_nan=True)    # bin sums: another grouping
+        for a, b in zip(g["pk_4"][0], np.array(want_pk)):
+            assert np.allclose(a, b, rtol=1e-10, atol=0, equal_nan=True)
+    if world > 1:                                                # the same numbers for every number of ranks
+        one = tmp_path / "one"
+        one.mkdir()
+        _chunk_worker(0, 1, _free_port(), str(one))
+        ref = np.load(str(one / "ch1_0.npz"))
+        assert np.array_equal(np.concatenate([g["dx2_4"] for g in got], axis=0), ref["dx2_4"])
+        assert np.allclose(got[0]["pk_4"], ref["pk_4"], rtol=1e-12, atol=0, equal_nan=True)
+
+
 def test_shell_thresholds_reproduce_digitize():
     """Host tables handed to the device: the threshold form equals np.digitize on every shell
     that is not flagged ambiguous, for several box sizes (edge-on-a-shell cases included)."""

@@ -307,3 +307,94 @@ def test_slab_path_at_2048(P, single_gpu_2048):
     del boxes, res
     gc.collect()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("f64", 1e-11)])
+@pytest.mark.parametrize("P,N,C", [(1, 64, 2), (2, 64, 3), (8, 64, 2), (4, 128, 5), (2, 256, 4)])
+def test_chunked_slab_transform_on_virtual_ranks(P, N, C, precision, tol):
+    """One transform in C chunks along k_z (fb_slab_*_chunk: the x and y passes over a range of tile columns, chunk arrays
+    with their own row pitch on the exchange side): the field bit-identical to the unchunked slab path, both against
+    the single-GPU box."""
+    from fastbox_amd import CosmoBox, default_cosmo, hostgeom
+    from fastbox_amd.distributed import HipSlabOps, SlabBox, run_virtual, run_virtual_chunked
+    L, seed, nb = 1e3, 41, 20
+    ref = CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, precision=precision, rng="device", seed=seed)
+    want_dx = np.asarray(ref.realise_density())
+    want = ref.binned_power_spectrum(delta_x=ref.lognormal(ref.delta_x), nbins=nb)
+    mk = lambda chunks: [SlabBox(default_cosmo, box_scale=L, nsamp=N, precision=precision, seed=seed, rank=r, world=P,
+                                 ops_factory=lambda g, PP, rr: HipSlabOps(g, PP, rr, precision=precision, device=0),
+                                 chunks=chunks) for r in range(P)]
+    boxes = mk(C)
+    assert all(b.chunks == C for b in boxes)
+    for b in boxes:
+        b._pk_setup(nb, None)
+    res = run_virtual_chunked(boxes, nb, True)
+    dx = np.concatenate([b.delta_x.double().cpu().numpy() for b in boxes], axis=0)
+    assert np.max(np.abs(dx - want_dx)) < tol * np.std(want_dx)
+    h = sum(r.cpu().numpy() for r in res)
+    mean = h[2 * nb] / float(N) ** 3
+    pk, err = hostgeom.finish_bins(boxes[0].ops.bin_counts(), h[0:2 * nb:2] / mean ** 2, h[1:2 * nb:2] / mean ** 4,
+                                   boxes[0].boxfactor)
+    m = ~np.isnan(want[1])
+    ptol = 1e-5 if precision == "f32" else 1e-10
+    assert np.array_equal(np.isnan(pk), np.isnan(want[1])) and np.allclose(pk[m], want[1][m], rtol=ptol, atol=0)
+    # the unchunked slab path: the same field bit for bit, the same sums to fp64 rounding of another grouping
+    plain = mk(1)
+    for b in plain:
+        b._pk_setup(nb, None)
+
+    def turn(b, recv):
+        b._res = b.ops.new_results(2 * nb + 1)
+        b.delta_x = b.ops.new_real()
+        b._send2 = b._kslab if recv is b._xbuf else b._xbuf
+        b.ops.turnaround(recv, b._half, b.delta_x, b._send2, True, b._res[2 * nb:])
+        return b._send2
+    run_virtual(plain, lambda b: b._gen_local(), turn)
+    dx1 = np.concatenate([b.delta_x.double().cpu().numpy() for b in plain], axis=0)
+    assert np.array_equal(dx, dx1)
+    res1 = run_virtual(plain, lambda b: b._send2, lambda b, kslab: b._pk_finish(kslab, nb).clone())
+    h1 = sum(r.cpu().numpy() for r in res1)
+    assert np.allclose(h, h1, rtol=1e-12, atol=0)
+    if P == 1:              # the public calls on one rank (no exchange: a chunk's send buffer is its receive buffer)
+        b = mk(C)[0]
+        kc, pk1, err1 = b.realise_and_power(nbins=nb, lognormal=True)
+        assert np.allclose(pk1[m], want[1][m], rtol=ptol, atol=0)
+        b._realisation = 0
+        d2 = b.realise_density().double().cpu().numpy()
+        assert np.array_equal(d2, dx)
+        kc, pk2, err2 = b.binned_power_spectrum(nbins=nb, lognormal=True)
+        assert np.allclose(pk2[m], want[1][m], rtol=ptol, atol=0)
+
+
+@pytest.mark.parametrize("P,C", [(2, 4), (8, 2)])
+def test_chunked_slab_transform_at_1024(P, C):
+    """BASELINE config 4's size, one box in C chunks over P virtual ranks (8 points per thread, 8-column tiles: 65 tile
+    columns, uneven chunks), compared with the single-GPU box through device reductions."""
+    import gc
+    import torch
+    from fastbox_amd import CosmoBox, default_cosmo, hostgeom
+    from fastbox_amd.distributed import HipSlabOps, SlabBox, run_virtual_chunked
+    N, L, seed, nb = 1024, 1e3, 19, 20
+    ref = CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, precision="f32", rng="device", seed=seed)
+    dx = ref.realise_density()
+    want_sq, want_sum = ref.engine.sum_real(dx, squared=True), ref.engine.sum_real(dx)
+    want = ref.binned_power_spectrum(delta_x=ref.lognormal(dx), nbins=nb)
+    del dx
+    ref.engine.close()
+    gc.collect()
+    boxes = [SlabBox(default_cosmo, box_scale=L, nsamp=N, precision="f32", seed=seed, rank=r, world=P,
+                     ops_factory=lambda g, PP, rr: HipSlabOps(g, PP, rr, precision="f32", device=0), chunks=C)
+             for r in range(P)]
+    for b in boxes:
+        b._pk_setup(nb, None)
+    res = run_virtual_chunked(boxes, nb, True)
+    got_sq = sum(float(torch.linalg.vector_norm(b.delta_x.reshape(-1), 2, dtype=torch.float64)) ** 2 for b in boxes)
+    got_sum = sum(float(torch.sum(b.delta_x, dtype=torch.float64)) for b in boxes)
+    assert np.isclose(got_sq, want_sq, rtol=1e-6) and abs(got_sum - want_sum) < 1e-6 * np.sqrt(want_sq * float(N) ** 3)
+    h = sum(r.cpu().numpy() for r in res)
+    assert hostgeom.lognormal_sums_in_range(boxes[0].ops.bin_counts(), h[0:2 * nb:2], h[1:2 * nb:2], h[2 * nb])
+    mean = h[2 * nb] / float(N) ** 3
+    pk, err = hostgeom.finish_bins(boxes[0].ops.bin_counts(), h[0:2 * nb:2] / mean ** 2, h[1:2 * nb:2] / mean ** 4,
+                                   boxes[0].boxfactor)
+    m = ~np.isnan(want[1])
+    assert np.array_equal(np.isnan(pk), np.isnan(want[1])) and np.allclose(pk[m], want[1][m], rtol=1e-5, atol=0)
