@@ -730,7 +730,7 @@ __device__ __forceinline__ void rsd_wave_sync() {
 }
 
 template <typename T, int E>
-__global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
+__global__ __launch_bounds__(64 * FB_RSD_WAVES, (sizeof(T) == 4 && E <= 8) ? 5 : 1) void k_rsd_cells(
         const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise, T* __restrict__ out,
         const double* __restrict__ zgrid, double Hz, double sigma_nl, RngKey rkey, int nearest) {
     constexpr int N = E * 64;
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
     // lane takes the brackets below its cells into registers), then again for the minima.  Half the LDS of
     // keeping both, and LDS is what limits the number of resident waves here.
     u64* kex = reinterpret_cast<u64*>(smem) + N + w * N;                            // [N] per wave
-    T* vex = reinterpret_cast<T*>(smem + sizeof(double) * N * (1 + FB_RSD_WAVES)) + w * N;   // [N] per wave
+    T* vex = reinterpret_cast<T*>(smem + sizeof(double) * N * (1 + FB_RSD_WAVES)) + w * (N + 16);   // [N] per wave + a spare slot
     const long long los = (long long)blockIdx.x * FB_RSD_WAVES + w;                 // N*N % WAVES == 0
     const T* d = delta + los * N;
     const T* v = vz + los * N;
@@ -751,16 +751,25 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
     // few places from it: stored in cell order those are 8 E bytes apart from lane to lane -- an E-way bank conflict on
     // every one of the ~110 LDS instructions per line; transposed, lane l's e-th cell is word l of row e.
     auto sw = [](int c) { return (c % E) * 64 + c / E; };
-    for (int m = threadIdx.x; m < N; m += 64 * FB_RSD_WAVES) zg[sw(m)] = zgrid[m];
+    // Single-precision plans work in a shifted frame: positions are measured from zmin and moved up by the length of the
+    // line, p = (z - zmin) + len in [len, 2 len).  Positive doubles order like their bit patterns, so the order-
+    // preserving encoding of the keys is the bit pattern itself (0 and ~0 stay free as the "empty cell" marks), and
+    // the wrap is a fract().  Differences of positions -- all the interpolation needs -- do not see the shift.
+    constexpr bool SHIFTED = sizeof(T) == 4;
+    const double zmin = zgrid[0], zmax = zgrid[N - 1];
+    const double len = zmax - zmin;
+    for (int m = threadIdx.x; m < N; m += 64 * FB_RSD_WAVES) zg[sw(m)] = SHIFTED ? (zgrid[m] - zmin) + len : zgrid[m];
 #pragma unroll
     for (int e = 0; e < E; ++e) kex[lane + 64 * e] = 0ull;
     __syncthreads();
-    const double zmin = zg[sw(0)], zmax = zg[sw(N - 1)];
-    const double len = zmax - zmin;
     const double inv_dz = (double)(N - 1) / len;
     [[maybe_unused]] const double inv_Hz = 1.0 / Hz, inv_len = 1.0 / len;
+    [[maybe_unused]] const double len_below = __longlong_as_double(__double_as_longlong(len) - 1);   // largest double < len
+    auto enc = [](double x) -> u64 { if constexpr (SHIFTED) return (u64)__double_as_longlong(x); else return order_bits(x); };
+    auto dec = [](u64 b) -> double { if constexpr (SHIFTED) return __longlong_as_double((long long)b); else return order_value(b); };
     u64 kb[E];
-    int cell[E];
+    int cell[E], cfin[E];
+    int unsettled = 0;
     T val[E];
     T nz[E];
     if (sigma_nl > 0.0) {
@@ -797,16 +806,23 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
 #pragma clang fp contract(off)
         const int m = lane * E + e;
         double vel = (double)vin[e];
-        if (sigma_nl > 0.0) vel = vel + sigma_nl * (double)nz[e];
+        // (asm: keeps the wave-uniform case a scalar branch -- if-converted, its three fp64 instructions would run for
+        // every cell of every call)
+        if (sigma_nl > 0.0) { asm volatile(""); vel = vel + sigma_nl * (double)nz[e]; }
+        if constexpr (SHIFTED) {
+            // the inputs carry 1e-7 relative error: reciprocals replace the two fp64 divisions (displacement, wrap), the
+            // wrap is a fract(), and the cell follows from the position itself -- a key within rounding (1e-13 cells) of a
+            // grid point may sit in the neighbouring cell, which moves an interpolation weight by that much
+            const double a = fma(-vel, inv_Hz, zg[lane + 64 * e] - len);         // z_m - zmin - vel / H
+            double r = __builtin_amdgcn_fract(a * inv_len) * len;                 // in [0, len]
+            r = r < len_below ? r : len_below;
+            int c = (int)(r * inv_dz);
+            cfin[e] = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
+            kb[e] = enc(r + len);
+            continue;
+        }
         double r;
-        if constexpr (sizeof(T) == 4) {
-            // single-precision plans: the inputs carry 1e-7 relative error, so reciprocals replace the two
-            // fp64 divisions (displacement, wrap); the wrap still lands in [0, len)
-            const double a = (zg[sw(m)] - vel * inv_Hz) - zmin;
-            r = fma(-floor(a * inv_len), len, a);
-            if (r < 0.0) r += len;
-            if (r >= len) r -= len;
-        } else {
+        {
             const double s = zg[sw(m)] - vel / Hz;
             r = fmod_pos(s - zmin, len);              // numpy % : result takes the divisor's sign
             if (r != 0.0) { if (r < 0.0) r += len; } else r = 0.0;
@@ -814,22 +830,47 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         const double key = r + zmin;
         int c = (int)((key - zmin) * inv_dz);
         c = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
-        // settle on z_c <= key < z_{c+1}: the estimate is off by at most one cell, so one step down and
-        // one step up without branches; the loops only run if that was not enough (never observed)
-        c -= (c > 0 && key < zg[sw(c)]) ? 1 : 0;
-        c += (c < N - 1 && key >= zg[sw(c + 1)]) ? 1 : 0;
-        if (__builtin_expect((c > 0 && key < zg[sw(c)]) || (c < N - 1 && key >= zg[sw(c + 1)]), 0)) {
+        // settle on z_c <= key < z_{c+1}: the estimate is off by at most one cell, so one step down or one step up --
+        // with unconditional LDS reads and selects, no branches: a CU issues ONE scalar instruction per cycle for all
+        // its waves (tools/salu_rate.hip), and the exec-mask bookkeeping of per-lane branches here (round 2: ~175
+        // scalar instructions per cell) was what bounded this kernel, not its arithmetic.  Whether that one step was
+        // enough is checked with a third read and, for the whole wave at once, after the loop (never observed).
+        // (asm: the value is "used" here, so the read stays unconditional -- the compiler would otherwise sink it
+        // behind the comparison that needs it and branch around it)
+        double zc = zg[sw(c)];
+        asm volatile("" : "+v"(zc));
+        const int down = (int)(key < zc);                 // (c = 0: z_0 = zmin <= key, never)
+        c -= down;
+        double zn = zg[sw(c < N - 1 ? c + 1 : N - 1)];
+        asm volatile("" : "+v"(zn));
+        const int up = (down ^ 1) & (int)(c < N - 1) & (int)(key >= zn);
+        c += up;
+        double zx = zg[sw(down ? c : (c < N - 1 ? c + 1 : N - 1))];
+        asm volatile("" : "+v"(zx));
+        unsettled |= (down & (int)(key < zx)) | (up & (int)(c < N - 1) & (int)(key >= zx));
+        cfin[e] = c;
+        kb[e] = enc(key);
+    }
+    if (__builtin_expect(__any(unsettled), 0)) {       // wave-uniform: walk to the cell that holds the key
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double key = dec(kb[e]);
+            int c = cfin[e];
             for (int it = 0; it < N && c > 0 && key < zg[sw(c)]; ++it) --c;
             for (int it = 0; it < N && c < N - 1 && key >= zg[sw(c + 1)]; ++it) ++c;
+            cfin[e] = c;
         }
-        kb[e] = order_bits(key);
-        cell[e] = sw(c);                              // from here on the cell's LDS index
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        cell[e] = sw(cfin[e]);                          // from here on the cell's LDS index
         atomicMax(&kex[cell[e]], kb[e]);
     }
     rsd_wave_sync();
+    // (the key that won a cell attaches its value: an unconditional store, the losers' to a spare slot behind the
+    // wave's array -- a per-lane branch would cost exec-mask bookkeeping on the scalar unit)
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (kex[cell[e]] == kb[e]) vex[cell[e]] = val[e];
+    for (int e = 0; e < E; ++e) vex[kex[cell[e]] == kb[e] ? cell[e] : N] = val[e];
     const double fill = 0.5 * ((double)d[0] + (double)d[N - 1]);
     rsd_wave_sync();
     // nearest non-empty cell strictly below / at-or-above each of this lane's cells
@@ -838,7 +879,9 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         cmx[e] = kex[lane + 64 * e];
-        if (cmx[e] != 0ull) { last = lane * E + e; if (first == N) first = lane * E + e; }
+        const bool occ = cmx[e] != 0ull;
+        first = (occ && first == N) ? lane * E + e : first;
+        last = occ ? lane * E + e : last;
     }
     int below = last, above = first;                  // inclusive scans over lanes: max from the left, min from the right
 #pragma unroll
@@ -855,7 +898,7 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
     {
         int a = nxt_above;
 #pragma unroll
-        for (int e = E - 1; e >= 0; --e) { if (cmx[e] != 0ull) a = lane * E + e; ab[e] = a; }
+        for (int e = E - 1; e >= 0; --e) { a = (cmx[e] != 0ull) ? lane * E + e : a; ab[e] = a; }
     }
     // lower bracket of every cell of this lane: (largest key, its value) of the nearest occupied cell below
     u64 pk[E];
@@ -869,7 +912,7 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
             const int q = sw(rb < 0 ? 0 : rb);
             pk[e] = kex[q];
             pv[e] = vex[q];
-            if (cmx[e] != 0ull) rb = lane * E + e;
+            rb = (cmx[e] != 0ull) ? lane * E + e : rb;
         }
     }
     rsd_wave_sync();
@@ -881,8 +924,7 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
     for (int e = 0; e < E; ++e) atomicMin(&kex[cell[e]], kb[e]);
     rsd_wave_sync();
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (kex[cell[e]] == kb[e]) vex[cell[e]] = val[e];
+    for (int e = 0; e < E; ++e) vex[kex[cell[e]] == kb[e] ? cell[e] : N] = val[e];
     rsd_wave_sync();
     T y_out[E];
 #pragma unroll
@@ -893,21 +935,31 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES) void k_rsd_cells(
         const bool filled = cmx[e] != 0ull;
         const int run_below = rbv[e];
         const u64 cmn_e = kex[c];
-        double y;
+        double y = 0.0;
         if constexpr (sizeof(T) == 4) {
-            // branch-free: bracket indices clamped into range, the three cases selected at the end
-            const bool exact = filled && order_value(cmn_e) == x;
-            const bool nofill = run_below >= 0 && ab[e] < N;
+            // branch-free and in single precision but for the two key differences: bracket indices clamped into range,
+            // every LDS read unconditional (asm: the value counts as used, so the compiler cannot sink the read behind a
+            // per-lane branch -- exec-mask bookkeeping runs on the CU's one scalar unit, which is what bounded this
+            // kernel), the cases selected at the end
+            const bool exact = filled & (dec(cmn_e) == x);
+            const bool nofill = (run_below >= 0) & (ab[e] < N);
             const int ra = sw(ab[e] < N ? ab[e] : N - 1);
-            const double kj = order_value(pk[e]), kn = order_value(kex[ra]);
-            const float vj = pv[e], vn = vex[ra];
+            u64 kna = kex[ra];
+            float vn = vex[ra], vc = vex[c];
+            asm volatile("" : "+v"(kna), "+v"(vn), "+v"(vc));
+            const double kj = dec(pk[e]), kn = dec(kna);
+            const float vj = pv[e];
             // differences in fp64 (close keys cancel), the quotient in fp32
             const float w = (float)(x - kj) * __builtin_amdgcn_rcpf((float)(kn - kj));
             float yi = vj + (vn - vj) * w;
             yi = (yi != yi && vj == vn) ? vj : yi;
-            y = exact ? (double)vex[c] : (nofill ? (double)yi : fill);
-            if (nearest && !exact)                    // see k_rsd: the nearer bracket, the lower one on a midpoint
-                y = (run_below < 0) ? (double)vn : ((ab[e] >= N) ? (double)vj : ((kj * 0.5 + kn * 0.5 < x) ? (double)vn : (double)vj));
+            float yl = nofill ? yi : (float)fill;
+            if (nearest) {                            // (wave-uniform) see k_rsd: the nearer bracket, the lower one on a midpoint
+                asm volatile("");                     // (a scalar branch, not four if-converted fp64 instructions per cell)
+                yl = (run_below < 0) ? vn : ((ab[e] >= N) ? vj : ((kj * 0.5 + kn * 0.5 < x) ? vn : vj));
+            }
+            y_out[e] = exact ? vc : yl;
+            continue;
         } else {
             if (filled && order_value(cmn_e) == x) y = (double)vex[c];
             else if (nearest) {
