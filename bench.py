@@ -448,6 +448,13 @@ def main():
             p.result()
         prof = eng.profile_stop()
         plain_launches = prof["fft_strided"][1]
+        # the other kernels of the step in the same un-overlapped way (one stream, every launch bracketed): the fused
+        # generator pass, the fused binning pass and the fused z pass -- the two that sit farthest from the roofline
+        # belong in this line, not only in profiles/
+        eng.profile_start(["fft_gen", "fft_bin", "fft_contig"], stride=1)
+        for p in [one() for _ in range(prof_steps)]:
+            p.result()
+        prof_other = eng.profile_stop()
         # the same kernel in the launches one box per GPU would use (plane batches sized to the whole Infinity Cache:
         # a launch carries a fixed fill and drain, so the larger launch reads closer to the kernel's own rate)
         big = None
@@ -534,6 +541,22 @@ def main():
                              "on-die: this is L2 <-> fabric bandwidth; the whole-step figure (pipeline_roofline) is the HBM statement"},
         "from_profiles": fp,
     }
+    if not in_region:
+        half = float(N) * N * (N // 2) * 2 * s                      # one sweep of the packed work spectrum = of the real field
+        for key, cls, nbytes, what in (
+                ("roofline_gen", "fft_gen", half, "k_fft_strided<GEN>: Philox noise + sqrt(P) colouring + first inverse pass (x); writes the work spectrum"),
+                ("roofline_bin", "fft_bin", half, "k_fft_strided<BIN>: last forward pass (x) + |delta_k|^2 shell binning; reads the work spectrum"),
+                ("roofline_z", "fft_contig", 3 * half, "k_fft_contig<C2R2C>: inverse z pass, delta_x stored, exp(), forward z pass (per plane batch: "
+                                                       "reads 1/2 sweep, writes 2 x 1/2)")):
+            ms_c, n_c = prof_other.get(cls, (0.0, 0))
+            if n_c and ms_c > 0:
+                per_step = n_c / float(prof_steps)                  # launches per step (the z pass: one per plane batch)
+                us = 1e3 * ms_c / n_c
+                ach = nbytes / per_step / (us * 1e-6) / 1e9
+                line[key] = {"bound": "hbm", "kernel": what, "algorithmic_bytes": nbytes / per_step, "avg_launch_us": us,
+                             "launches_timed": n_c, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ach / HBM_PEAK_GBS, "timed_in": "separate pass of %d steps on ONE stream before the "
+                             "warm-up steps, every launch bracketed with HIP events" % prof_steps}
     if not in_region and big and big[1]:
         b_alg = 2 * (2.0 * N * N * ncols * 2 * s) * big[2] / big[1]
         b_ach = b_alg / (big[0] / big[1] * 1e-3) / 1e9

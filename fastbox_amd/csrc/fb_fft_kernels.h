@@ -327,9 +327,17 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             auto column = [&](const int kz, auto j0_tag, auto nj_tag, auto acc_tag) {
                 constexpr int J0 = decltype(j0_tag)::value, NJ = decltype(nj_tag)::value;
                 constexpr bool ACC = decltype(acc_tag)::value;
-                const bool plane = (kz == 0) || (kz == H);
-                const bool flip = plane && ky > H;         // drawn as the conjugate of the mirror image's draw
-                const int kyd = flip ? N - ky : ky;
+                // (has_plane is wave-uniform: 14 of 16 tiles hold neither self-mirrored plane, and the per-lane selects of the
+                // mirror-image draws -- 30 to 40 vector instructions per thread -- are skipped there by scalar branches;
+                // the asm keeps them branches)
+                bool plane = false, flip = false;          // flip: drawn as the conjugate of the mirror image's draw
+                int kyd = ky;
+                if (has_plane) {
+                    asm volatile("");
+                    plane = (kz == 0) || (kz == H);
+                    flip = plane && ky > H;
+                    kyd = flip ? N - ky : ky;
+                }
                 // lo(j), hi(j): where pair j's two modes are formed (v[] itself, or temporaries of the ACC call)
                 cx<T> wl[ACC ? NJ : 1], wh[ACC ? NJ : 1];
                 auto lo = [&](int j) -> cx<T>& { if constexpr (ACC) return wl[j - J0]; else return v[j]; };
@@ -385,10 +393,15 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     T a0, a1, b0, b1;
                     box_muller(X[j - J0][0], X[j - J0][1], a0, a1);
                     box_muller(X[j - J0][2], X[j - J0][3], b0, b1);
-                    const bool sw = flip && (t + j * TPL) > 0;      // the mirror images of (g, g + N/2) are (N/2 - g) + N/2, N/2 - g
-                    lo(j) = cx<T>{sw ? b0 : a0, sw ? b1 : a1};
-                    hi(j) = cx<T>{sw ? a0 : b0, sw ? a1 : b1};
-                    if (flip) { lo(j).y = -lo(j).y; hi(j).y = -hi(j).y; }
+                    lo(j) = cx<T>{a0, a1};
+                    hi(j) = cx<T>{b0, b1};
+                    if (has_plane) {
+                        asm volatile("");
+                        const bool sw = flip && (t + j * TPL) > 0;      // the mirror images of (g, g + N/2) are (N/2 - g) + N/2, N/2 - g
+                        lo(j) = cx<T>{sw ? b0 : a0, sw ? b1 : a1};
+                        hi(j) = cx<T>{sw ? a0 : b0, sw ? a1 : b1};
+                        if (flip) { lo(j).y = -lo(j).y; hi(j).y = -hi(j).y; }
+                    }
                 }
                 if (has_plane && rowself) {
                     // rows k_y = 0, N/2 of a plane mirror onto themselves: k_x in (0, N/2) is drawn, k_x + N/2 is the
