@@ -1,0 +1,65 @@
+// Tuning aid: copy / read / write rates of the 2048^3 strided-pass tile pattern (2048 rows x 64 B per workgroup) for
+// different placements of the rows: the [x][k_y][k_z] half spectrum as it is (y rows 8 KB apart, x rows 17 MB apart),
+// and a tile-major layout [k_z tile][x][k_y (+pad)][8 columns] (y tile contiguous, x rows 128 KB (+pad) apart).
+//   hipcc --offload-arch=gfx950 -O3 tools/stride_copy_2048.hip -o /tmp/sc2048 && /tmp/sc2048
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+__global__ __launch_bounds__(1024) void k_tile(const char* __restrict__ in, char* __restrict__ out, long long stride,
+                                               long long outer_stride, long long tile_stride, int seg, int rows, int ntx, int ntiles, int mode) {
+    const int lanes_per_row = seg / 8;
+    const int r0 = threadIdx.x / lanes_per_row, c = threadIdx.x % lanes_per_row;
+    const int rstep = blockDim.x / lanes_per_row;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = (long long)(tile / ntx) * outer_stride + (long long)(tile % ntx) * tile_stride + c * 8;
+        for (int r = r0; r < rows; r += rstep * 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (mode != 2 && r + u * rstep < rows) ? *(const double*)(in + base + (long long)(r + u * rstep) * stride) : 1.0;
+            if (mode == 1) { double acc = 0; for (int u = 0; u < 16; ++u) acc += v[u]; if (acc == 1.2345) out[0] = 1; }
+            else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (r + u * rstep < rows) *(double*)(out + base + (long long)(r + u * rstep) * stride) = v[u];
+            }
+        }
+    }
+}
+
+int main() {
+    const long long N = 2048, NZP = 1040, NR = 2049, seg = 64;
+    const long long bytes = N * NR * NZP * 8 + (64ll << 20) + 2048ll * 2100 * 64 * 131;    // room for the padded tile-major variants
+    char *a, *b;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    hipMemset(a, 1, bytes); hipMemset(b, 0, bytes);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    struct Cfg { const char* name; long long stride, outer, tile; int nouter, ntx; };
+    const long long row = NZP * 8, plane = NR * row;
+    Cfg cfgs[] = {
+        {"now  y pass (rows 8320 B apart, tiles of a plane adjacent)", row, plane, seg, 256, 130},
+        {"now  x pass (rows 17.0 MB apart)                          ", plane, row, seg, 256, 130},
+        {"TM   y pass (tile contiguous: 128 KB)                     ", seg, N * seg, N * N * seg, 256, 130},
+        {"TM   x pass (rows 128 KB apart, no pad)                   ", N * seg, seg, N * N * seg, 256, 130},
+        {"TM   x pass (rows 128 KB + 64 B apart)                   ", (N + 1) * seg, seg, N * (N + 1) * seg, 256, 130},
+        {"TM   x pass (rows 128 KB + 256 B apart)                  ", (N + 4) * seg, seg, N * (N + 4) * seg, 256, 130},
+        {"TM   x pass (rows 128 KB + 2112 B apart)                 ", (N + 33) * seg, seg, N * (N + 33) * seg, 256, 130},
+        {"TM   y pass with the 33-row pad                           ", seg, (N + 33) * seg, N * (N + 33) * seg, 256, 130},
+    };
+    for (auto& cf : cfgs)
+        for (int mode : {0, 1, 2}) {
+            const int ntiles = cf.ntx * cf.nouter;                      // 256 of the 2048 outer indices: 1/8 of a pass
+            const double moved = 2.0 * (double)ntiles * seg * N;
+            for (int blocks : {256, 512}) {
+                float best = 1e9f;
+                for (int rep = 0; rep < 4; ++rep) {
+                    hipEventRecord(e0);
+                    hipLaunchKernelGGL(k_tile, dim3(blocks), dim3(1024), 0, 0, a, b, cf.stride, cf.outer, cf.tile, (int)seg, (int)N, cf.ntx, ntiles, mode);
+                    hipEventRecord(e1); hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    if (ms < best) best = ms;
+                }
+                printf("%s %s %4d blocks: %8.1f us  %6.0f GB/s\n", cf.name, mode == 0 ? "copy " : (mode == 1 ? "read " : "write"), blocks,
+                       best * 1e3, (mode == 0 ? moved : moved / 2) / best / 1e6);
+            }
+        }
+    return 0;
+}
