@@ -719,7 +719,13 @@ __device__ __forceinline__ double fmod_pos(double a, double b) {
     return r;
 }
 
-constexpr int FB_RSD_WAVES = 4;
+#ifndef FB_RSD_WAVES_SMALL
+#define FB_RSD_WAVES_SMALL 4      // lines of sight (waves) per workgroup up to 8 cells per lane (tuning: 8 with FB_RSD_OCC 6)
+#endif
+#ifndef FB_RSD_OCC
+#define FB_RSD_OCC 5              // waves per SIMD the single-precision kernel is compiled for, up to 8 cells per lane
+#endif
+constexpr int rsd_waves(int E) { return E <= 8 ? FB_RSD_WAVES_SMALL : 4; }
 
 // A line of sight is one wave's: its key / value arrays are touched by no other wave, and a wave's LDS instructions
 // (atomics included) execute in issue order, so between the phases the compiler only has to be kept from reordering
@@ -730,10 +736,11 @@ __device__ __forceinline__ void rsd_wave_sync() {
 }
 
 template <typename T, int E>
-__global__ __launch_bounds__(64 * FB_RSD_WAVES, (sizeof(T) == 4 && E <= 8) ? 5 : 1) void k_rsd_cells(
+__global__ __launch_bounds__(64 * rsd_waves(E), (sizeof(T) == 4 && E <= 8) ? FB_RSD_OCC : 1) void k_rsd_cells(
         const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise, T* __restrict__ out,
         const double* __restrict__ zgrid, double Hz, double sigma_nl, RngKey rkey, int nearest) {
     constexpr int N = E * 64;
+    constexpr int FB_RSD_WAVES = rsd_waves(E);
     typedef unsigned long long u64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -874,14 +881,16 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES, (sizeof(T) == 4 && E <= 8) ? 5 :
     const double fill = 0.5 * ((double)d[0] + (double)d[N - 1]);
     rsd_wave_sync();
     // nearest non-empty cell strictly below / at-or-above each of this lane's cells
-    u64 cmx[E];
+    // (which of this lane's cells are occupied: one bit each -- the maxima themselves are only needed as "non-empty", and
+    // eight 64-bit registers less are what lets a sixth wave per SIMD in)
+    unsigned occ = 0;
     int last = -1, first = N;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        cmx[e] = kex[lane + 64 * e];
-        const bool occ = cmx[e] != 0ull;
-        first = (occ && first == N) ? lane * E + e : first;
-        last = occ ? lane * E + e : last;
+        const bool o = kex[lane + 64 * e] != 0ull;
+        occ |= o ? (1u << e) : 0u;
+        first = (o && first == N) ? lane * E + e : first;
+        last = o ? lane * E + e : last;
     }
     int below = last, above = first;                  // inclusive scans over lanes: max from the left, min from the right
 #pragma unroll
@@ -898,21 +907,21 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES, (sizeof(T) == 4 && E <= 8) ? 5 :
     {
         int a = nxt_above;
 #pragma unroll
-        for (int e = E - 1; e >= 0; --e) { a = (cmx[e] != 0ull) ? lane * E + e : a; ab[e] = a; }
+        for (int e = E - 1; e >= 0; --e) { a = ((occ >> e) & 1u) ? lane * E + e : a; ab[e] = a; }
     }
     // lower bracket of every cell of this lane: (largest key, its value) of the nearest occupied cell below
     u64 pk[E];
     T pv[E];
-    int rbv[E];
+    unsigned has_below = 0;                           // bit e: there is an occupied cell below this lane's e-th cell
     {
         int rb = run_below;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            rbv[e] = rb;
+            has_below |= rb >= 0 ? (1u << e) : 0u;
             const int q = sw(rb < 0 ? 0 : rb);
             pk[e] = kex[q];
             pv[e] = vex[q];
-            rb = (cmx[e] != 0ull) ? lane * E + e : rb;
+            rb = ((occ >> e) & 1u) ? lane * E + e : rb;
         }
     }
     rsd_wave_sync();
@@ -932,8 +941,8 @@ __global__ __launch_bounds__(64 * FB_RSD_WAVES, (sizeof(T) == 4 && E <= 8) ? 5 :
 #pragma clang fp contract(off)
         const int c = lane + 64 * e;                   // LDS index of cell lane E + e
         const double x = zg[c];
-        const bool filled = cmx[e] != 0ull;
-        const int run_below = rbv[e];
+        const bool filled = (occ >> e) & 1u;
+        const int run_below = ((has_below >> e) & 1u) ? 0 : -1;         // (only its sign is used)
         const u64 cmn_e = kex[c];
         double y = 0.0;
         if constexpr (sizeof(T) == 4) {
