@@ -61,6 +61,9 @@ SIGNATURES = {
     "fb_power_spectrum_filtered": (c_int, [c_void_p, c_void_p, c_void_p, c_int, P_double, c_void_p, c_void_p, c_void_p]),
     "fb_power_spectrum_filtered_field": (c_int, [c_void_p, c_void_p, c_void_p, c_int, P_double, c_void_p, c_void_p, c_void_p]),
     "fb_fft_c2r_yz": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p]),
+    "fb_realise_velocity_begin": (c_int, [c_void_p, c_u64, c_u64, c_int, c_double, c_void_p, c_void_p]),
+    "fb_power_spectrum_redshift_space": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double,
+                                                 c_u64, c_int, c_int, P_double, c_void_p, c_int, c_void_p, c_void_p]),
     "fb_power_spectrum_pending": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "fb_power_spectrum_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fb_bin_counts": (c_int, [c_void_p, P_double]),

@@ -214,6 +214,43 @@ class PendingDensity(DeviceArray):
         return self._buf.ptr
 
 
+class RedshiftSpaceField(DeviceArray):
+    """``redshift_space_density`` of two device-generator realisations (density, v_z) whose last FFT passes have not run
+    yet.  Reading it finishes both and runs the remap kernel; asking for the power spectrum of its transform -- directly,
+    or through ``apply_transfer_fn(to_k(...))`` -- instead runs ONE z pass per line of sight that finishes both inverse
+    transforms, remaps and starts the forward transform (``Engine.power_redshift_space``): v_z in real space and this
+    field itself are then never written.  The numbers are the same bit for bit."""
+
+    def __init__(self, engine, delta, vz, args):
+        DeviceArray.__init__(self, engine, REAL, None)
+        self.delta, self.vz, self.args = delta, vz, args      # args = (Hz, sigma_nl, seed, method)
+
+    @property
+    def materialised(self):
+        return self._buf is not None
+
+    def fusable(self):
+        return self._buf is None and self.delta is not self.vz and all(
+            isinstance(f, PendingDensity) and not f.materialised and f._pending is not None for f in (self.delta, self.vz))
+
+    def consume(self, filt=None, field=False):
+        """The fused pass: (results buffer, work half spectrum); delta_x is filled in, v_z's pending spectrum is gone
+        (reading v_z later draws it again)."""
+        Hz, sigma_nl, seed, method = self.args
+        res, real, work = self.engine.power_redshift_space(self.delta._pending, self.vz._pending, Hz, sigma_nl, seed, method,
+                                                           filt=filt, field=field)
+        self.delta._adopt(real)
+        self.vz._pending = None
+        return res, work
+
+    @property
+    def ptr(self):
+        if self._buf is None:
+            Hz, sigma_nl, seed, method = self.args
+            self._buf = self.engine.redshift_space(self.delta, self.vz, Hz, sigma_nl, None, seed, method)._buf
+        return self._buf.ptr
+
+
 class CosmoBox(object):
 
     def __init__(self, cosmo, box_scale=1e3, nsamp=32, redshift=0.,
@@ -337,6 +374,19 @@ class CosmoBox(object):
             # velocity of a device-RNG realisation: regenerate delta_k inside the first inverse pass
             amp_key, seed, realisation, comp, fac = field_k.recipe
             self._set_amplitude(*amp_key)
+            if comp == 2 and self.engine.fuses_redshift_space:
+                # v_z: the last passes are deferred -- redshift_space_density of it can then finish them inside its own
+                # kernel (RedshiftSpaceField); reading the field runs them as before
+                wbox = weakref.ref(self)
+
+                def again():
+                    box = wbox()
+                    if box is None:
+                        raise RuntimeError("the CosmoBox that drew this field is gone; it cannot be drawn again")
+                    box._set_amplitude(*amp_key)
+                    return box.engine.realise_velocity_fused(seed, realisation, comp, fac)
+                return PendingDensity(self.engine, self.engine.realise_velocity_begin(seed, realisation, comp, fac),
+                                      regenerate=again)
             return self.engine.realise_velocity_fused(seed, realisation, comp, fac)
         f = self._as_spectrum(field_k)
         if f.kind == HALF:
@@ -550,6 +600,10 @@ class CosmoBox(object):
             # the reference draws N normals per line of sight in (i, j) order (box.py:416-418)
             noise = self.engine.upload(np.random.normal(0., 1., (self.N, self.N, self.N)), REAL)
         seed = self.seed + 0x9E3779B97F4A7C15 * (self._realisation + 1)
+        if noise is None and self.engine.fuses_redshift_space:
+            lazy = RedshiftSpaceField(self.engine, d, v, (Hz, sigma_nl, seed, method))
+            if lazy.fusable():
+                return lazy
         return self.engine.redshift_space(d, v, Hz, sigma_nl, noise, seed, method)
 
     # ------------------------------------------------------------------- log-normal
@@ -622,7 +676,11 @@ class CosmoBox(object):
                     and isinstance(src, LazySpectrum) and src.source_real is not None and not src.materialised:
                 # what apply_transfer_fn returns is the field (box.py:381): the pass that filters and bins an x line
                 # also transforms it back, and reading the field later costs the y and z passes only
-                res, root._x_done = eng.power_filtered(src.source_real, filt, field=True)
+                rs = src.source_real
+                if isinstance(rs, RedshiftSpaceField) and rs.fusable():
+                    res, root._x_done = rs.consume(filt, field=True)       # the z passes of the whole chain in one kernel
+                else:
+                    res, root._x_done = eng.power_filtered(rs, filt, field=True)
                 pending = PendingSpectrum(eng, res, bins.size, kc, self.boxfactor, None, None)
                 return pending if not wait else pending.result()
             cnt, s1, s2 = eng.bin_power(src, filt=filt)
@@ -669,7 +727,9 @@ class CosmoBox(object):
                     exact = hostgeom.lognormal_shift_exact(eng.max_real(field), nvox)   # (materialises a pending field)
                     res2, _ = eng.power_fused(field, pre_exp=True, exp_shift=exact)
                     return eng.fetch_results(res2, nb_)
-            if isinstance(src, PendingDensity) and not src.materialised and src._pending is not None:
+            if isinstance(src, RedshiftSpaceField) and src.fusable() and not ln:
+                res, _ = src.consume()
+            elif isinstance(src, PendingDensity) and not src.materialised and src._pending is not None:
                 res, real = eng.power_pending(src._pending, pre_exp=ln, exp_shift=shift, keep_field=keep_field)     # z passes fused
                 if real is not None:
                     src._adopt(real)

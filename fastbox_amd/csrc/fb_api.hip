@@ -393,6 +393,32 @@ int fb_power_spectrum_filtered_field(fb_plan* p, const void* real_in, void* work
     return FB_DISPATCH(p, fbi_power_filtered_f32(p, real_in, work_half, kind, params, table_dev, (double*)results_dev, 1, s),
                        fbi_power_filtered_f64(p, real_in, work_half, kind, params, table_dev, (double*)results_dev, 1, s));
 }
+int fb_realise_velocity_begin(fb_plan* p, uint64_t seed, uint64_t realisation, int comp, double fac, void* pending_half,
+                              void* stream) {
+    FB_REQUIRE(p && pending_half, "null pointer");
+    FB_USE_DEVICE(p);
+    FB_REQUIRE(comp >= 0 && comp <= 2, "component must be 0, 1 or 2");
+    FB_REQUIRE(p->N % 2 == 0, "velocity needs an even grid size");
+    hipStream_t s = (hipStream_t)stream;
+    return FB_DISPATCH(p, fbi_realise_velocity_begin_f32(p, seed, realisation, comp, fac, pending_half, s),
+                       fbi_realise_velocity_begin_f64(p, seed, realisation, comp, fac, pending_half, s));
+}
+int fb_power_spectrum_redshift_space(fb_plan* p, void* pending_delta, void* pending_vz, void* delta_x_out, void* work_half,
+                                     double Hz, double sigma_nl, uint64_t seed, int method, int filter_kind,
+                                     const double* params, const void* table_dev, int want_field, void* results_dev,
+                                     void* stream) {
+    FB_REQUIRE(p && pending_delta && pending_vz && work_half && results_dev, "null pointer");   // delta_x_out may be NULL
+    FB_USE_DEVICE(p);
+    FB_REQUIRE(Hz > 0, "Hz must be positive");
+    FB_REQUIRE(method == FB_RSD_LINEAR || method == FB_RSD_NEAREST, "method: FB_RSD_LINEAR or FB_RSD_NEAREST");
+    FB_REQUIRE(pending_delta != pending_vz && work_half != pending_delta && work_half != pending_vz, "three distinct half spectra");
+    hipStream_t s = (hipStream_t)stream;
+    const double scale = 1.0 / ((double)p->N * p->N * p->N);
+    return FB_DISPATCH(p, fbi_power_redshift_space_f32(p, pending_delta, pending_vz, delta_x_out, work_half, scale, Hz, sigma_nl, seed,
+                                                       method, filter_kind, params, table_dev, (double*)results_dev, want_field, s),
+                       fbi_power_redshift_space_f64(p, pending_delta, pending_vz, delta_x_out, work_half, scale, Hz, sigma_nl, seed,
+                                                    method, filter_kind, params, table_dev, (double*)results_dev, want_field, s));
+}
 int fb_fft_c2r_yz(fb_plan* p, void* half, void* out, double scale, void* stream) {
     FB_REQUIRE(p && half && out, "null pointer");
     FB_USE_DEVICE(p);

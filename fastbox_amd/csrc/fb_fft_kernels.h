@@ -869,6 +869,68 @@ template <int NF> constexpr int contig_lines() {   // lines per workgroup
     return fb_max(1, FB_CONTIG_THREADS / (NF / elems_per_thread(NF)));
 }
 
+// ---- one line of the contiguous (z) axis through the packed half-length complex transform ----------------------
+// (shared by k_fft_contig and the fused redshift-space z pass k_rsd_turn: the same instructions, so the same bits)
+// c2r: the half-spectrum row `in` (N/2 + 1 entries, or N/2 with entry 0 = X[0] + i X[N/2] when packed) -> the real line,
+// thread t of the line's NF / E threads ending with v[e] = (x[2j], x[2j+1]) * scale, j = t + e NF / E.
+//   Z[k] = (X[k] + conj X[n-k]) + i e^{+2 pi i k/N} (X[k] - conj X[n-k]); the imaginary parts of X[0], X[n] are dropped
+//   (Hermitian projection).  twl = W_{2 NF}^j in LDS, published before the call.
+template <typename T, int NF, bool WAVE>
+__device__ __forceinline__ void c2r_line(const cx<T>* __restrict__ in, const int packed, const int t, const cx<T>* twl,
+                                         const LineLayout<T>& lay, const T scale, cx<T> (&v)[elems_per_thread(NF)]) {
+    constexpr int E = elems_per_thread(NF), TPL = NF / E;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = t + e * TPL;
+        cx<T> xk = in[k], xn = in[packed ? ((NF - k) & (NF - 1)) : NF - k];
+        if (k == 0) { if (packed) xn.x = xk.y; xk.y = 0; xn.y = 0; }
+        if constexpr (sizeof(T) == 4) {          // packed forms: s + i conj(w) d in five instructions
+            const cx<T> s = pk_add_conj(xk, xn), d = pk_sub_conj(xk, xn);
+            v[e] = pk_add_i<+1>(s, pk_cmul<+1>(d, twl[k]));
+        } else {
+            cx<T> s = xk + cconj(xn), d = xk - cconj(xn);
+            cx<T> w = cconj(twl[k]);
+            cx<T> wd = cmul(w, d);
+            v[e] = cx<T>{s.x - wd.y, s.y + wd.x};
+        }
+    }
+    fft_stages<T, NF, E, +1, 2, 1, LineLayout<T>, WAVE>(v, t, twl, lay);
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = cscale(v[e], scale);
+}
+// r2c: v[e] = (x[2j], x[2j+1]) of a real line -> its half-spectrum row at `out` (nullptr: nothing is stored), times sc.
+//   X[k] = (Z[k] + conj Z[n-k])/2 - (i/2) W_N^k (Z[k] - conj Z[n-k])
+template <typename T, int NF, bool WAVE>
+__device__ __forceinline__ void r2c_line(cx<T> (&v)[elems_per_thread(NF)], const int t, const cx<T>* twl, const LineLayout<T>& lay,
+                                         const int packed, cx<T>* __restrict__ out, const T sc) {
+    constexpr int E = elems_per_thread(NF), TPL = NF / E;
+    fft_stages<T, NF, E, -1, 2, 1, LineLayout<T>, WAVE>(v, t, twl, lay);
+#pragma unroll
+    for (int e = 0; e < E; ++e) lay.at(t + e * TPL) = v[e];
+    exchange_sync<WAVE>();
+    if (out) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = t + e * TPL;
+            cx<T> zk = v[e];
+            cx<T> res;
+            if constexpr (sizeof(T) == 4) {      // (s - i w d) / 2 with s = z_k + conj z_{n-k}, d = z_k - conj z_{n-k}
+                const cx<T> zr = lay.at((NF - k) & (NF - 1));
+                const cx<T> s = pk_add_conj(zk, zr), d = pk_sub_conj(zk, zr);
+                res = cscale(pk_add_i<-1>(s, pk_cmul<-1>(d, twl[k])), (T)0.5 * sc);
+            } else {
+                cx<T> zn = cconj(lay.at((NF - k) & (NF - 1)));
+                cx<T> s = zk + zn, d = zk - zn;
+                cx<T> wd = cmul(twl[k], d);
+                res = cx<T>{(T)0.5 * (s.x + wd.y) * sc, (T)0.5 * (s.y - wd.x) * sc};
+            }
+            if (k == 0 && packed) out[0] = cx<T>{(zk.x + zk.y) * sc, (zk.x - zk.y) * sc};
+            else out[k] = res;
+            if (k == 0 && !packed) out[NF] = cx<T>{(zk.x - zk.y) * sc, (T)0};
+        }
+    }
+}
+
 // NF = complex transform length (N for c2c, N/2 for r2c/c2r)
 template <typename T, int NF, int MODE>
 __global__ __launch_bounds__(contig_lines<NF>() * (NF / elems_per_thread(NF)))
@@ -907,24 +969,7 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
         // (taking the untangle twiddles straight from the global table, so that the line's own loads are not held behind
         // this barrier, was measured slower: 0.3245 against 0.3062 ms per step for the fused z pass)
         __syncthreads();
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int k = t + e * TPL;
-            cx<T> xk = in[k], xn = in[a.packed ? ((NF - k) & (NF - 1)) : NF - k];
-            if (k == 0) { if (a.packed) xn.x = xk.y; xk.y = 0; xn.y = 0; }
-            if constexpr (sizeof(T) == 4) {          // packed forms: s + i conj(w) d in five instructions
-                const cx<T> s = pk_add_conj(xk, xn), d = pk_sub_conj(xk, xn);
-                v[e] = pk_add_i<+1>(s, pk_cmul<+1>(d, twl[k]));
-            } else {
-                cx<T> s = xk + cconj(xn), d = xk - cconj(xn);
-                cx<T> w = cconj(twl[k]);
-                cx<T> wd = cmul(w, d);
-                v[e] = cx<T>{s.x - wd.y, s.y + wd.x};
-            }
-        }
-        fft_stages<T, NF, E, +1, TWS, 1, LineLayout<T>, WAVE>(v, t, twl, lay);
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = cscale(v[e], a.scale);
+        c2r_line<T, NF, WAVE>(in, a.packed, t, twl, lay, a.scale, v);
         if (valid && a.out) {                          // C2R2C with no real output: the field is only passed on
             cx<T>* out = reinterpret_cast<cx<T>*>(reinterpret_cast<T*>(a.out) + line * a.out_pitch);
 #pragma unroll
@@ -959,35 +1004,12 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
         }
         if constexpr (MODE == ZMODE_R2C || !WAVE) __syncthreads();      // R2C: the twiddles; C2R2C: lines[] is this wave's own
         else exchange_sync<true>();
-        fft_stages<T, NF, E, -1, TWS, 1, LineLayout<T>, WAVE>(v, t, twl, lay);
-        // untangle: X[k] = (Z[k] + conj Z[n-k])/2 - (i/2) W_N^k (Z[k] - conj Z[n-k])
-#pragma unroll
-        for (int e = 0; e < E; ++e) lay.at(t + e * TPL) = v[e];
-        exchange_sync<WAVE>();
-        if (valid) {
+        {
             cx<T>* out = (MODE == ZMODE_C2R2C)
                 ? reinterpret_cast<cx<T>*>(a.out2) + (line + (a.in_skip ? line / a.in_skip : 0)) * a.in_pitch
                 : reinterpret_cast<cx<T>*>(a.out) + (line + (a.out_skip ? line / a.out_skip : 0)) * a.out_pitch;
             const T sc = (MODE == ZMODE_C2R2C) ? (T)1 : a.scale;     // C2R2C: `scale` belongs to the inverse half
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int k = t + e * TPL;
-                cx<T> zk = v[e];
-                cx<T> res;
-                if constexpr (sizeof(T) == 4) {      // (s - i w d) / 2 with s = z_k + conj z_{n-k}, d = z_k - conj z_{n-k}
-                    const cx<T> zr = lay.at((NF - k) & (NF - 1));
-                    const cx<T> s = pk_add_conj(zk, zr), d = pk_sub_conj(zk, zr);
-                    res = cscale(pk_add_i<-1>(s, pk_cmul<-1>(d, twl[k])), (T)0.5 * sc);
-                } else {
-                    cx<T> zn = cconj(lay.at((NF - k) & (NF - 1)));
-                    cx<T> s = zk + zn, d = zk - zn;
-                    cx<T> wd = cmul(twl[k], d);
-                    res = cx<T>{(T)0.5 * (s.x + wd.y) * sc, (T)0.5 * (s.y - wd.x) * sc};
-                }
-                if (k == 0 && a.packed) out[0] = cx<T>{(zk.x + zk.y) * sc, (zk.x - zk.y) * sc};
-                else out[k] = res;
-                if (k == 0 && !a.packed) out[NF] = cx<T>{(zk.x - zk.y) * sc, (T)0};
-            }
+            r2c_line<T, NF, WAVE>(v, t, twl, lay, a.packed, valid ? out : nullptr, sc);
         }
         if (a.pre_exp) {                       // wave-uniform
             __syncthreads();                   // lines[] no longer needed
@@ -1012,6 +1034,152 @@ void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
             cx<T>* out = reinterpret_cast<cx<T>*>(a.out) + (line + (a.out_skip ? line / a.out_skip : 0)) * a.out_pitch;
 #pragma unroll
             for (int e = 0; e < E; ++e) out[t + e * TPL] = cscale(v[e], a.scale);
+        }
+    }
+}
+
+// ---- redshift-space z pass: c2r(delta) + c2r(v_z) + line-of-sight remap + r2c in one kernel -------------------------
+// The chain  realise_density -> realise_velocity[2] -> redshift_space_density -> fftn  (BASELINE configs[2],
+// examples/example_redshift_space.py + box.py:384-438) turns round on the z axis: both inverse transforms end with a z
+// pass, the remap works along z, the forward transform starts with one.  One wave per line of sight does all four on
+// the line while it is on the chip: lanes 0 .. NF/8-1 take the inverse z transform of delta's row and the next NF/8
+// lanes that of v_z's row (the instructions of k_fft_contig, c2r_line), the two real lines are handed over through LDS
+// so that lane l owns cells l E .. l E + E - 1 of both (k_rsd_cells' ownership), the remap runs as in k_rsd_cells
+// (rsd_remap_line), and the first lanes take the forward z transform of the result (r2c_line).  delta_x is written for
+// the caller; v_z in real space, the redshift-space field and two reads of delta_x never touch memory: 4 half-sweeps
+// of traffic instead of 9 (the three z passes 2 each, the remap 3).  Bit-identical to the separate kernels.
+// Single-precision plans, 64 <= N <= 512 (both rows' transforms fit one wave; per-wave LDS as k_rsd_cells).
+#ifndef FB_RSDT_WAVES
+#define FB_RSDT_WAVES 4           // lines of sight (waves) per workgroup
+#endif
+#ifndef FB_RSDT_ZG_LDS
+#define FB_RSDT_ZG_LDS 0          // 1: the grid in LDS as in k_rsd_cells (4 KiB more per workgroup at N = 512: one resident
+                                  // workgroup fewer per CU); 0: each lane reads its own E grid points from the (cached) table
+#endif
+template <typename T> struct RsdTurnArgs {
+    const cx<T>* in_d;        // delta's work spectrum after the inverse x and y passes: rows `pitch` apart, one spare row per N
+    const cx<T>* in_v;        // v_z's, same layout
+    T* dx_out;                // [nlines][N] delta_x of these lines, or null
+    cx<T>* out;               // forward z spectrum of the remapped lines: N/2 + 1 entries per row, same row layout
+    const cx<T>* tw;          // W_N^j, N entries
+    const double* zgrid;      // [N]
+    long long pitch;
+    long long nlines, line0;  // lines of this launch (a plane batch); global index of the first (the noise's counters)
+    T scale_d, scale_v;
+    int packed_in;            // in_d / in_v rows: entry 0 = X[0] + i X[N/2], N/2 entries
+    double Hz, sigma_nl;
+    RngKey rkey;
+    int nearest;
+};
+template <int E> constexpr size_t rsd_turn_region() { return (size_t)8 * 64 * E + 4 * (64 * E + 16); }   // per wave: keys + values
+template <int E> constexpr size_t rsd_turn_lds() {
+    return (size_t)(FB_RSDT_ZG_LDS ? 16 : 8) * 64 * E + FB_RSDT_WAVES * rsd_turn_region<E>();
+}
+template <typename T, int E>
+__global__ __launch_bounds__(64 * FB_RSDT_WAVES, FB_RSD_OCC) void k_rsd_turn(RsdTurnArgs<T> a) {
+    static_assert(sizeof(T) == 4 && E >= 1 && E <= 8, "single precision, 64 <= N <= 512");
+    constexpr int N = 64 * E, NF = N / 2, EF = elems_per_thread(NF), TPL = NF / EF;
+    constexpr int LP = LineLayout<T>::padded(NF);
+    static_assert(2 * TPL <= 64 && 2 * LP * sizeof(cx<T>) <= rsd_turn_region<E>() && 2 * N * sizeof(T) <= rsd_turn_region<E>(), "layout");
+    typedef unsigned long long u64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    cx<T>* twl = reinterpret_cast<cx<T>*>(smem);                                     // [N]   shared by the block
+    [[maybe_unused]] double* zgl = reinterpret_cast<double*>(smem + (size_t)8 * N);   // [N]   (FB_RSDT_ZG_LDS)
+    char* mine = smem + (size_t)(FB_RSDT_ZG_LDS ? 16 : 8) * N + w * rsd_turn_region<E>();
+    u64* kex = reinterpret_cast<u64*>(mine);                                         // [N]      this wave's
+    T* vex = reinterpret_cast<T*>(mine + (size_t)8 * N);                             // [N + 16] this wave's
+    cx<T>* fl = reinterpret_cast<cx<T>*>(mine);        // the transforms' line buffers ([2][LP]) and
+    T* rl = reinterpret_cast<T*>(mine);                // the two real lines ([2][N]) live in the same bytes, before the remap
+    const double zmin = a.zgrid[0], zmax = a.zgrid[N - 1];
+    const double len = zmax - zmin;
+    for (int i = threadIdx.x; i < N; i += 64 * FB_RSDT_WAVES) twl[i] = a.tw[i];
+    if constexpr (FB_RSDT_ZG_LDS) {
+        auto sw = [](int c) { return (c % E) * 64 + c / E; };
+        for (int m = threadIdx.x; m < N; m += 64 * FB_RSDT_WAVES) zgl[sw(m)] = (a.zgrid[m] - zmin) + len;
+    }
+    __syncthreads();                                   // the only workgroup barrier: from here on a wave is on its own
+    const long long ll = (long long)blockIdx.x * FB_RSDT_WAVES + w;
+    if (ll >= a.nlines) return;
+    const long long row = ll + ll / N;
+    // inverse z transforms: lanes [0, TPL) delta, [TPL, 2 TPL) v_z
+    {
+        const int l = lane / TPL, t = lane % TPL;
+        cx<T> v[EF];
+        if (2 * TPL == 64 || l < 2) {
+            const cx<T>* in = (l ? a.in_v : a.in_d) + row * a.pitch;
+            const LineLayout<T> lay{fl + (l & 1) * LP};
+#if defined(FB_RSDT_KNOCK) && (FB_RSDT_KNOCK & 1)      // tuning aid: no inverse transforms
+#pragma unroll
+            for (int e = 0; e < EF; ++e) v[e] = cscale(in[t + e * TPL], l ? a.scale_v : a.scale_d);
+#else
+            c2r_line<T, NF, true>(in, a.packed_in, t, twl, lay, l ? a.scale_v : a.scale_d, v);
+#endif
+        }
+        exchange_sync<true>();
+        if (2 * TPL == 64 || l < 2) {
+#pragma unroll
+            for (int e = 0; e < EF; ++e) reinterpret_cast<cx<T>*>(rl + (l & 1) * N)[t + e * TPL] = v[e];
+        }
+        exchange_sync<true>();
+    }
+    T val[E], vin[E];
+    if constexpr (E % 4 == 0) {
+        typedef T vec4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) {
+            const vec4 b = reinterpret_cast<const vec4*>(rl + lane * E)[q], c = reinterpret_cast<const vec4*>(rl + N + lane * E)[q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { val[4 * q + u] = b[u]; vin[4 * q + u] = c[u]; }
+            // (streaming store: the chain does not read delta_x again)
+            if (a.dx_out) __builtin_nontemporal_store(b, reinterpret_cast<vec4*>(a.dx_out + ll * N + lane * E) + q);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { val[e] = rl[lane * E + e]; vin[e] = rl[N + lane * E + e]; }
+        if (a.dx_out) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) __builtin_nontemporal_store(val[e], a.dx_out + ll * N + lane * E + e);
+        }
+    }
+    rsd_wave_sync();
+#pragma unroll
+    for (int e = 0; e < E; ++e) kex[lane + 64 * e] = 0ull;
+    rsd_wave_sync();
+    // (delta[0] + delta[N-1]) / 2: lane 0's first and lane 63's last cell
+    const T d0 = __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[0]), 0));
+    const T dn = __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[E - 1]), 63));
+    const double fill = 0.5 * ((double)d0 + (double)dn);
+    T y_out[E];
+#if defined(FB_RSDT_KNOCK) && (FB_RSDT_KNOCK & 2)      // tuning aid: no remap
+#pragma unroll
+    for (int e = 0; e < E; ++e) y_out[e] = val[e] + vin[e] * (T)fill;
+#else
+    rsd_remap_line<T, E, !FB_RSDT_ZG_LDS>(vin, val, nullptr, a.line0 + ll, fill, FB_RSDT_ZG_LDS ? zgl : a.zgrid, kex, vex, zmin, len, a.Hz,
+                                          a.sigma_nl, a.rkey, a.nearest, lane, y_out);
+#endif
+    rsd_wave_sync();
+    // forward z transform of the remapped line: cells (2 j, 2 j + 1) are point j of the half-length complex sequence
+    {
+        const LineLayout<T> lay{fl};
+        if constexpr (E % 2 == 0) {
+#pragma unroll
+            for (int q = 0; q < E / 2; ++q) lay.at(lane * (E / 2) + q) = cx<T>{y_out[2 * q], y_out[2 * q + 1]};
+        } else {
+            reinterpret_cast<T*>(&lay.at(lane >> 1))[lane & 1] = y_out[0];
+        }
+        exchange_sync<true>();
+        if (lane < TPL) {
+            cx<T> v[EF];
+#pragma unroll
+            for (int e = 0; e < EF; ++e) v[e] = lay.at(lane + e * TPL);
+            exchange_sync<true>();
+#if defined(FB_RSDT_KNOCK) && (FB_RSDT_KNOCK & 4)      // tuning aid: no forward transform
+#pragma unroll
+            for (int e = 0; e < EF; ++e) (a.out + row * a.pitch)[lane + e * TPL] = v[e];
+#else
+            r2c_line<T, NF, true>(v, lane, twl, lay, 0, a.out + row * a.pitch, (T)1);
+#endif
         }
     }
 }

@@ -735,40 +735,27 @@ __device__ __forceinline__ void rsd_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename T, int E>
-__global__ __launch_bounds__(64 * rsd_waves(E), (sizeof(T) == 4 && E <= 8) ? FB_RSD_OCC : 1) void k_rsd_cells(
-        const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise, T* __restrict__ out,
-        const double* __restrict__ zgrid, double Hz, double sigma_nl, RngKey rkey, int nearest) {
+// The remap of ONE line of sight by one wave.  On entry: vin[] / val[] = this lane's E consecutive velocities / densities
+// (cells lane E .. lane E + E - 1), zg[] = the grid in the kernel's frame and LDS order (see k_rsd_cells), kex[] zeroed,
+// all of it published to the wave; fill = (delta[0] + delta[N-1]) / 2 (np.interp outside the samples, box.py:433).
+// On exit y_out[] = the lane's E cells of the redshift-space line; kex / vex are free again.  (Shared by k_rsd_cells and
+// by the fused z pass k_rsd_turn of fb_fft_kernels.h, which must give bit-identical lines.)
+template <typename T, int E, bool ZG_GLOBAL = false>
+__device__ __forceinline__ void rsd_remap_line(const T (&vin)[E], const T (&val)[E], const T* __restrict__ noise, const long long los,
+                                               const double fill, const double* zg, unsigned long long* kex, T* vex,
+                                               const double zmin, const double len, const double Hz, const double sigma_nl,
+                                               const RngKey rkey, const int nearest, const int lane, T (&y_out)[E]) {
     constexpr int N = E * 64;
-    constexpr int FB_RSD_WAVES = rsd_waves(E);
     typedef unsigned long long u64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double* zg = reinterpret_cast<double*>(smem);                                   // [N]       shared by the block
-    // one key array and one value array per wave, used twice: first for the per-cell maxima (from which each
-    // lane takes the brackets below its cells into registers), then again for the minima.  Half the LDS of
-    // keeping both, and LDS is what limits the number of resident waves here.
-    u64* kex = reinterpret_cast<u64*>(smem) + N + w * N;                            // [N] per wave
-    T* vex = reinterpret_cast<T*>(smem + sizeof(double) * N * (1 + FB_RSD_WAVES)) + w * (N + 16);   // [N] per wave + a spare slot
-    const long long los = (long long)blockIdx.x * FB_RSD_WAVES + w;                 // N*N % WAVES == 0
-    const T* d = delta + los * N;
-    const T* v = vz + los * N;
-    // LDS layout: cell c lives at index sw(c) = (c % E) 64 + c / E.  Lane l owns the E consecutive cells l E .. l E + E-1
-    // (one 16/32-byte global load each way), and nearly every LDS access of the kernel is "my e-th cell" or a cell a
-    // few places from it: stored in cell order those are 8 E bytes apart from lane to lane -- an E-way bank conflict on
-    // every one of the ~110 LDS instructions per line; transposed, lane l's e-th cell is word l of row e.
-    auto sw = [](int c) { return (c % E) * 64 + c / E; };
-    // Single-precision plans work in a shifted frame: positions are measured from zmin and moved up by the length of the
-    // line, p = (z - zmin) + len in [len, 2 len).  Positive doubles order like their bit patterns, so the order-
-    // preserving encoding of the keys is the bit pattern itself (0 and ~0 stay free as the "empty cell" marks), and
-    // the wrap is a fract().  Differences of positions -- all the interpolation needs -- do not see the shift.
     constexpr bool SHIFTED = sizeof(T) == 4;
-    const double zmin = zgrid[0], zmax = zgrid[N - 1];
-    const double len = zmax - zmin;
-    for (int m = threadIdx.x; m < N; m += 64 * FB_RSD_WAVES) zg[sw(m)] = SHIFTED ? (zgrid[m] - zmin) + len : zgrid[m];
-#pragma unroll
-    for (int e = 0; e < E; ++e) kex[lane + 64 * e] = 0ull;
-    __syncthreads();
+    auto sw = [](int c) { return (c % E) * 64 + c / E; };
+    static_assert(!ZG_GLOBAL || SHIFTED, "the grid is read from the plan's table by the single-precision path only");
+    // position of this lane's e-th cell in the kernel's frame: from the LDS copy, or (ZG_GLOBAL: zg = the plan's table in
+    // global memory, 8 N bytes that stay in the vector cache) formed as the LDS copy is
+    auto zown = [&](int e) -> double {
+        if constexpr (ZG_GLOBAL) return (zg[lane * E + e] - zmin) + len;
+        else return zg[lane + 64 * e];
+    };
     const double inv_dz = (double)(N - 1) / len;
     [[maybe_unused]] const double inv_Hz = 1.0 / Hz, inv_len = 1.0 / len;
     [[maybe_unused]] const double len_below = __longlong_as_double(__double_as_longlong(len) - 1);   // largest double < len
@@ -777,7 +764,6 @@ __global__ __launch_bounds__(64 * rsd_waves(E), (sizeof(T) == 4 && E <= 8) ? FB_
     u64 kb[E];
     int cell[E], cfin[E];
     int unsettled = 0;
-    T val[E];
     T nz[E];
     if (sigma_nl > 0.0) {
         const unsigned long long idx0 = (unsigned long long)los * N + lane * E;
@@ -793,21 +779,6 @@ __global__ __launch_bounds__(64 * rsd_waves(E), (sizeof(T) == 4 && E <= 8) ? FB_
             for (int e = 0; e < E; ++e) nz[e] = los_noise_at<T>(idx0 + e, rkey);
         }
     }
-    // this lane's E consecutive velocities and densities in 16-byte loads (a lane's cells are contiguous)
-    T vin[E];
-    if constexpr (E * sizeof(T) % 16 == 0) {
-        typedef T vec16 __attribute__((ext_vector_type(16 / sizeof(T))));
-        constexpr int PER = 16 / sizeof(T);
-#pragma unroll
-        for (int q = 0; q < E / PER; ++q) {
-            const vec16 a = reinterpret_cast<const vec16*>(v + lane * E)[q], b = reinterpret_cast<const vec16*>(d + lane * E)[q];
-#pragma unroll
-            for (int u = 0; u < PER; ++u) { vin[q * PER + u] = a[u]; val[q * PER + u] = b[u]; }
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < E; ++e) { vin[e] = v[lane * E + e]; val[e] = d[lane * E + e]; }
-    }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
 #pragma clang fp contract(off)
@@ -820,7 +791,7 @@ __global__ __launch_bounds__(64 * rsd_waves(E), (sizeof(T) == 4 && E <= 8) ? FB_
             // the inputs carry 1e-7 relative error: reciprocals replace the two fp64 divisions (displacement, wrap), the
             // wrap is a fract(), and the cell follows from the position itself -- a key within rounding (1e-13 cells) of a
             // grid point may sit in the neighbouring cell, which moves an interpolation weight by that much
-            const double a = fma(-vel, inv_Hz, zg[lane + 64 * e] - len);         // z_m - zmin - vel / H
+            const double a = fma(-vel, inv_Hz, zown(e) - len);                   // z_m - zmin - vel / H
             double r = __builtin_amdgcn_fract(a * inv_len) * len;                 // in [0, len]
             r = r < len_below ? r : len_below;
             int c = (int)(r * inv_dz);
@@ -878,7 +849,6 @@ __global__ __launch_bounds__(64 * rsd_waves(E), (sizeof(T) == 4 && E <= 8) ? FB_
     // wave's array -- a per-lane branch would cost exec-mask bookkeeping on the scalar unit)
 #pragma unroll
     for (int e = 0; e < E; ++e) vex[kex[cell[e]] == kb[e] ? cell[e] : N] = val[e];
-    const double fill = 0.5 * ((double)d[0] + (double)d[N - 1]);
     rsd_wave_sync();
     // nearest non-empty cell strictly below / at-or-above each of this lane's cells
     // (which of this lane's cells are occupied: one bit each -- the maxima themselves are only needed as "non-empty", and
@@ -935,12 +905,11 @@ __global__ __launch_bounds__(64 * rsd_waves(E), (sizeof(T) == 4 && E <= 8) ? FB_
 #pragma unroll
     for (int e = 0; e < E; ++e) vex[kex[cell[e]] == kb[e] ? cell[e] : N] = val[e];
     rsd_wave_sync();
-    T y_out[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
 #pragma clang fp contract(off)
         const int c = lane + 64 * e;                   // LDS index of cell lane E + e
-        const double x = zg[c];
+        const double x = zown(e);
         const bool filled = (occ >> e) & 1u;
         const int run_below = ((has_below >> e) & 1u) ? 0 : -1;         // (only its sign is used)
         const u64 cmn_e = kex[c];
@@ -989,6 +958,61 @@ __global__ __launch_bounds__(64 * rsd_waves(E), (sizeof(T) == 4 && E <= 8) ? FB_
         }
         y_out[e] = (T)y;
     }
+}
+
+template <typename T, int E>
+__global__ __launch_bounds__(64 * rsd_waves(E), (sizeof(T) == 4 && E <= 8) ? FB_RSD_OCC : 1) void k_rsd_cells(
+        const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise, T* __restrict__ out,
+        const double* __restrict__ zgrid, double Hz, double sigma_nl, RngKey rkey, int nearest) {
+    constexpr int N = E * 64;
+    constexpr int FB_RSD_WAVES = rsd_waves(E);
+    typedef unsigned long long u64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double* zg = reinterpret_cast<double*>(smem);                                   // [N]       shared by the block
+    // one key array and one value array per wave, used twice: first for the per-cell maxima (from which each
+    // lane takes the brackets below its cells into registers), then again for the minima.  Half the LDS of
+    // keeping both, and LDS is what limits the number of resident waves here.
+    u64* kex = reinterpret_cast<u64*>(smem) + N + w * N;                            // [N] per wave
+    T* vex = reinterpret_cast<T*>(smem + sizeof(double) * N * (1 + FB_RSD_WAVES)) + w * (N + 16);   // [N] per wave + a spare slot
+    const long long los = (long long)blockIdx.x * FB_RSD_WAVES + w;                 // N*N % WAVES == 0
+    const T* d = delta + los * N;
+    const T* v = vz + los * N;
+    // LDS layout: cell c lives at index sw(c) = (c % E) 64 + c / E.  Lane l owns the E consecutive cells l E .. l E + E-1
+    // (one 16/32-byte global load each way), and nearly every LDS access of the kernel is "my e-th cell" or a cell a
+    // few places from it: stored in cell order those are 8 E bytes apart from lane to lane -- an E-way bank conflict on
+    // every one of the ~110 LDS instructions per line; transposed, lane l's e-th cell is word l of row e.
+    auto sw = [](int c) { return (c % E) * 64 + c / E; };
+    // Single-precision plans work in a shifted frame: positions are measured from zmin and moved up by the length of the
+    // line, p = (z - zmin) + len in [len, 2 len).  Positive doubles order like their bit patterns, so the order-
+    // preserving encoding of the keys is the bit pattern itself (0 and ~0 stay free as the "empty cell" marks), and
+    // the wrap is a fract().  Differences of positions -- all the interpolation needs -- do not see the shift.
+    constexpr bool SHIFTED = sizeof(T) == 4;
+    const double zmin = zgrid[0], zmax = zgrid[N - 1];
+    const double len = zmax - zmin;
+    for (int m = threadIdx.x; m < N; m += 64 * FB_RSD_WAVES) zg[sw(m)] = SHIFTED ? (zgrid[m] - zmin) + len : zgrid[m];
+#pragma unroll
+    for (int e = 0; e < E; ++e) kex[lane + 64 * e] = 0ull;
+    __syncthreads();
+    T val[E];
+    // this lane's E consecutive velocities and densities in 16-byte loads (a lane's cells are contiguous)
+    T vin[E];
+    if constexpr (E * sizeof(T) % 16 == 0) {
+        typedef T vec16 __attribute__((ext_vector_type(16 / sizeof(T))));
+        constexpr int PER = 16 / sizeof(T);
+#pragma unroll
+        for (int q = 0; q < E / PER; ++q) {
+            const vec16 a = reinterpret_cast<const vec16*>(v + lane * E)[q], b = reinterpret_cast<const vec16*>(d + lane * E)[q];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) { vin[q * PER + u] = a[u]; val[q * PER + u] = b[u]; }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { vin[e] = v[lane * E + e]; val[e] = d[lane * E + e]; }
+    }
+    const double fill = 0.5 * ((double)d[0] + (double)d[N - 1]);
+    T y_out[E];
+    rsd_remap_line<T, E>(vin, val, noise, los, fill, zg, kex, vex, zmin, len, Hz, sigma_nl, rkey, nearest, lane, y_out);
 #pragma unroll
     for (int e = 0; e < E; ++e) out[los * N + lane * E + e] = y_out[e];
 }

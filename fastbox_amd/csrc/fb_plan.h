@@ -124,6 +124,11 @@ int fb_hip_check(hipError_t e, const char* what);
     int fbi_power_filtered_##sfx(fb_plan* p, const void* real_in, void* filtered_half, int kind, const double* prm, \
                                  const void* table, double* results, int inverse_x, hipStream_t s); \
     int fbi_fft_c2r_yz_##sfx(fb_plan* p, void* half_inout, void* real_out, double scale, hipStream_t s); \
+    int fbi_realise_velocity_begin_##sfx(fb_plan* p, uint64_t seed, uint64_t real, int comp, double fac, void* work_half, \
+                                         hipStream_t s); \
+    int fbi_power_redshift_space_##sfx(fb_plan* p, void* work_d, void* work_v, void* real_d_out, void* out_half, double scale, \
+                                       double Hz, double sigma_nl, uint64_t seed, int nearest, int kind, const double* prm, \
+                                       const void* table, double* results, int inverse_x, hipStream_t s); \
     int fbi_slab_forward_packed_##sfx(fb_plan* p, const void* real_local, void* half_local, void* xbuf, int nxl, \
                                       int nparts, int pre_exp, double* expsum, hipStream_t s); \
     int fbi_slab_inverse_packed_##sfx(fb_plan* p, const void* xbuf, void* half_local, void* real_local, int nxl, \

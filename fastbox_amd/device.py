@@ -8,6 +8,7 @@ only copied to the host (as float64 / complex128, the reference's dtypes) when
 numpy touches it (``np.asarray``, indexing, ufuncs).
 """
 import ctypes
+import os
 import weakref
 
 import numpy as np
@@ -504,6 +505,35 @@ class Engine(object):
         _lib.call("fb_realise_density_begin", self._plan, int(seed) & (2 ** 64 - 1),
                   int(realisation) & (2 ** 64 - 1), pend.ptr, self.stream)
         return pend
+
+    def realise_velocity_begin(self, seed, realisation, comp, fac):
+        """Generator + x pass of velocity component `comp` of the realisation; returns the pending half spectrum
+        (`realise_finish` runs its y and z passes, `power_redshift_space` consumes it)."""
+        pend = self.empty(HALF)
+        _lib.call("fb_realise_velocity_begin", self._plan, int(seed) & (2 ** 64 - 1), int(realisation) & (2 ** 64 - 1),
+                  int(comp), float(fac), pend.ptr, self.stream)
+        return pend
+
+    @property
+    def fuses_redshift_space(self):
+        """Does `power_redshift_space` exist for this plan?  (single precision, 64 <= N <= 512)"""
+        return self.precision == "f32" and 64 <= self.N <= 512 and (self.N & (self.N - 1)) == 0 \
+            and not os.environ.get("FASTBOX_NO_RSD_FUSION")          # (tuning aid: time the separate kernels)
+
+    def power_redshift_space(self, pend_delta, pend_vz, Hz, sigma_nl, seed, method, filt=None, field=False, keep_field=True):
+        """P(k) of the redshift-space density of two pending realisations (density, v_z), optionally through a
+        k_perp / k_par filter (kind, params): one z pass does both inverse transforms, the remap and the forward
+        transform.  Returns (results buffer, delta_x or None, work half spectrum: the filtered spectrum -- with `field`
+        transformed back along x, for `fft_c2r_yz` -- or scratch when there is no filter).  Both pendings are destroyed."""
+        res = self._result_slot()
+        real = self.empty(REAL) if keep_field else None
+        out = self.empty(HALF)
+        kind = -1 if filt is None else int(filt[0])
+        prm = (ctypes.c_double * 4)(*[float(x) for x in (filt[1] if filt is not None else (0, 0, 0, 0))])
+        _lib.call("fb_power_spectrum_redshift_space", self._plan, pend_delta.ptr, pend_vz.ptr,
+                  real.ptr if keep_field else None, out.ptr, float(Hz), float(sigma_nl), int(seed) & (2 ** 64 - 1),
+                  self.RSD_METHODS[method], kind, prm, None, 1 if field else 0, res.ptr, self.stream)
+        return res, real, out
 
     def realise_finish(self, pend):
         out = self.empty(REAL)

@@ -134,6 +134,26 @@ int fb_power_spectrum_filtered_field(fb_plan* plan, const void* real_in, void* w
                                      const double* params, const void* table_dev, void* results_dev, void* stream);
 int fb_fft_c2r_yz(fb_plan* plan, void* half_x_done, void* real_out, double scale, void* stream);
 
+/* BASELINE configs[2] as one chain (examples/example_redshift_space.py: realise_density, realise_velocity, box.py:384-438
+ * redshift_space_density, then np.fft.fftn of the result and box.py:356-381 / :696-768 on it), for a device-generator
+ * realisation.  fb_realise_velocity_begin: generator + first inverse pass of velocity component comp (fac = box.py:280-281),
+ * deferred like fb_realise_density_begin (fb_realise_density_finish delivers the component in real space).
+ * fb_power_spectrum_redshift_space: pending_delta / pending_vz (both destroyed) -> delta_x_out (the density in real space;
+ * NULL: not written), the P(k) sums of the redshift-space field in results_dev (as fb_power_spectrum_device), and, when
+ * filter_kind >= 0 (FB_FILT_TABLE, _BEAM_HIGHPASS, _WEDGE as fb_power_spectrum_filtered; -1: no filter, work_half is
+ * scratch), the filtered spectrum in work_half -- want_field: already transformed back along x, for fb_fft_c2r_yz.
+ * The two inverse z passes, the line-of-sight remap and the forward z pass are ONE kernel per plane batch: v_z in real
+ * space and the redshift-space field itself never reach memory (4 half-sweeps of traffic instead of 9).  The numbers are
+ * those of fb_realise_density_finish + fb_realise_velocity_device + fb_redshift_space + fb_power_spectrum_filtered[_field],
+ * bit for bit.  Hz, sigma_nl, seed, method: as fb_redshift_space (sigma_nl > 0 draws the device noise of that call).
+ * Single-precision plans with 64 <= N <= 512 (FB_ERR_UNSUPPORTED otherwise: use the separate calls).                  */
+int fb_realise_velocity_begin(fb_plan* plan, uint64_t seed, uint64_t realisation, int comp, double fac,
+                              void* pending_half, void* stream);
+int fb_power_spectrum_redshift_space(fb_plan* plan, void* pending_delta, void* pending_vz, void* delta_x_out,
+                                     void* work_half, double Hz, double sigma_nl, uint64_t seed, int method,
+                                     int filter_kind, const double* params, const void* table_dev, int want_field,
+                                     void* results_dev, void* stream);
+
 /* fused path for cubic boxes (needs fb_set_bins with thr): r2c of real_in (of exp(real_in) when
  * pre_exp) with the binning inside the last pass.  Asynchronous: results_dev[2*nbins+1] (DEVICE)
  * receives (sum |dk|^2, sum |dk|^4) per bin, then sum(exp(real_in)) (0 unless pre_exp).

@@ -1,0 +1,84 @@
+"""GPU: the fused z pass of BASELINE configs[2] (k_rsd_turn: the inverse z transforms of delta and v_z, the
+line-of-sight remap of box.py:384-438 and the forward z transform of the result in one kernel) against the separate
+kernels it replaces -- the same instructions on the same numbers, so every product of the chain must agree bit for
+bit: delta_x, v_z, the redshift-space field, the filtered field and the binned power spectrum.  (The separate kernels
+are pinned to the oracle in tests/test_config3_gpu.py and tests/test_derived_gpu.py; the 512^3 chain of
+test_config3_gpu.py runs through the fused pass and is held to the oracle there.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _box(N, seed=7, precision="f32"):
+    from fastbox_amd import CosmoBox, default_cosmo
+    return CosmoBox(cosmo=default_cosmo, box_scale=1e3 * N / 512., nsamp=N, realise_now=False, precision=precision,
+                    rng="device", seed=seed)
+
+
+def _chain(box, fused, method, sigma_nl, filtered=True):
+    from fastbox_amd import Wedge
+    from fastbox_amd.box import RedshiftSpaceField
+    dx = box.realise_density()
+    vz = box.to_real(box.realise_velocity()[2])
+    if not fused:
+        vz.ptr                                   # v_z finished on its own: the remap below runs as a kernel of its own
+    ds = box.redshift_space_density(delta_x=dx, velocity_z=vz, sigma_nl=sigma_nl, method=method)
+    assert isinstance(ds, RedshiftSpaceField) == fused
+    if filtered:
+        filt = box.apply_transfer_fn(box.to_k(ds), Wedge(slope=0.3))
+        pend = box.binned_power_spectrum(delta_x=filt.real, nbins=20, wait=False)
+        field = np.asarray(filt.real)
+    else:
+        pend = box.binned_power_spectrum(delta_x=ds, nbins=20, wait=False)
+        field = None
+    if fused:
+        assert not ds.materialised and dx.materialised and not vz.materialised     # one pass did it all
+    return pend.result(), np.asarray(dx), np.asarray(vz), np.asarray(ds), field
+
+
+@pytest.mark.parametrize("method,sigma_nl", [("linear", 0.0), ("nearest", 0.0), ("linear", 150.0)])
+@pytest.mark.parametrize("N", [64, 128, 256, 512])
+def test_fused_z_pass_equals_separate_kernels(N, method, sigma_nl):
+    a = _chain(_box(N), True, method, sigma_nl)
+    b = _chain(_box(N), False, method, sigma_nl)
+    for x, y, what in zip(a[1:], b[1:], ("delta_x", "v_z", "redshift-space field", "filtered field")):
+        assert np.array_equal(x, y), what
+    for x, y in zip(a[0], b[0]):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert np.all(np.isfinite(a[4])) and np.std(a[3]) > 0.1 * np.std(a[1])
+
+
+@pytest.mark.parametrize("N", [128, 512])
+def test_fused_z_pass_without_a_filter(N):
+    """binned_power_spectrum(delta_x=redshift_space_density(...)): the same pass, the binning x pass behind it.  The
+    separate path bins a packed work spectrum (other partial sums): float32 rounding between the two."""
+    a = _chain(_box(N, seed=3), True, "linear", 0.0, filtered=False)
+    b = _chain(_box(N, seed=3), False, "linear", 0.0, filtered=False)
+    for x, y in zip(a[1:4], b[1:4]):
+        assert np.array_equal(x, y)
+    m = ~np.isnan(b[0][1])
+    assert np.array_equal(np.isnan(a[0][1]), np.isnan(b[0][1])) and np.array_equal(a[0][0], b[0][0])
+    assert np.allclose(a[0][1][m], b[0][1][m], rtol=2e-6) and np.allclose(a[0][2][m], b[0][2][m], rtol=2e-5)
+
+
+def test_fused_z_pass_is_not_taken_where_it_does_not_exist():
+    """fp64 plans and fields that are already in memory go through the separate kernels."""
+    from fastbox_amd.box import RedshiftSpaceField
+    box = _box(64, precision="f64")
+    dx = box.realise_density()
+    vz = box.to_real(box.realise_velocity()[2])
+    assert not isinstance(box.redshift_space_density(delta_x=dx, velocity_z=vz), RedshiftSpaceField)
+    box = _box(64)
+    dx = box.realise_density()
+    vz = box.to_real(box.realise_velocity()[2])
+    ds = box.redshift_space_density(delta_x=np.asarray(dx), velocity_z=vz)
+    assert not isinstance(ds, RedshiftSpaceField)
+    # a lazy field whose density was consumed by another estimate in between: finished the ordinary way
+    dx = box.realise_density()
+    vz = box.to_real(box.realise_velocity()[2])
+    ds = box.redshift_space_density(delta_x=dx, velocity_z=vz)
+    box.binned_power_spectrum(delta_x=dx, nbins=12)
+    assert isinstance(ds, RedshiftSpaceField) and not ds.fusable()
+    k, pk, err = box.binned_power_spectrum(delta_x=ds, nbins=12)
+    assert np.all(np.isfinite(pk[~np.isnan(pk)])) and ds.materialised
