@@ -210,7 +210,9 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         }
     };
     auto store_rows = [&](cx<T>* dst, const unsigned voff, const cx<T> (&r)[E], const T scale) {
-        constexpr int AUX = MODE == SMODE_GEN ? FB_GEN_STORE_AUX : 0;
+        // (generator pass at N = 1024 -- 64-byte row segments written by one workgroup per tile: streaming stores, 2.30 ->
+        // 2.17 ms; no gain at 512, a loss under the resident schedule of 2048: profiles/r03_gen_store_variants.txt)
+        constexpr int AUX = MODE == SMODE_GEN ? ((N == 1024 && !PERSIST && sizeof(T) == 4) ? 2 : FB_GEN_STORE_AUX) : 0;
         if constexpr (BLK) {
 #pragma unroll
             for (int e = 0; e < E; ++e) buf_store<AUX>(make_rsrc(dst + eoff(e, a.blk_out, estep_o)), voff, 0u, cscale(r[e], scale));
