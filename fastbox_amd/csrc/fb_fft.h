@@ -179,13 +179,22 @@ constexpr int elems_per_thread(int n) { return fb_min(8, n); }
 // 8-lane (fp64) group always touches one contiguous 128-byte row, so both the
 // scattered writes and the linear reads are bank-conflict free.
 template <typename T, int TZ> struct TileLayout {
+    static constexpr bool split = false;
     cx<T>* base; int col;
     __device__ __forceinline__ cx<T>& at(int pos) const { return base[pos * TZ + col]; }
+};
+// The same tile at half the LDS: real parts and imaginary parts go through it one after the other (a thread keeps the
+// half that is not on its way in registers), so that a CU holds twice as many tiles -- or workgroups half the size.
+template <typename T, int TZ> struct SplitTileLayout {
+    static constexpr bool split = true;
+    T* base; int col;
+    __device__ __forceinline__ T& at(int pos) const { return base[pos * TZ + col]; }
 };
 // Contiguous-axis passes: one line per thread group, one pad element every 8
 // so that the radix-8 first-stage scatter (lane stride 8 elements) spreads
 // over all banks.
 template <typename T> struct LineLayout {
+    static constexpr bool split = false;
     cx<T>* base;
     static __host__ __device__ constexpr int padded(int n) { return n + (n >> 3) + 1; }
     __device__ __forceinline__ cx<T>& at(int pos) const { return base[pos + (pos >> 3)]; }
@@ -225,6 +234,34 @@ __device__ __forceinline__ void fft_stages(cx<T> (&v)[E], const int t, const cx<
         for (int q = 0; q < R; ++q) v[m + q * NB] = u[q];
     }
     if constexpr (P * R < N) {
+        if constexpr (Layout::split) {
+            // half-size tile: the real parts make the round trip, then the imaginary parts (which wait in v[].y, still in
+            // the old distribution, while v[].x already holds the new one)
+#pragma unroll
+            for (int m = 0; m < NB; ++m) {
+                const int i = t + m * TPL;
+                const int k = i & (P - 1);
+                const int j = (i - k) * R + k;
+#pragma unroll
+                for (int q = 0; q < R; ++q) lds.at(j + q * P) = v[m + q * NB].x;
+            }
+            exchange_sync<WAVE>();
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e].x = lds.at(t + e * TPL);
+            exchange_sync<WAVE>();
+#pragma unroll
+            for (int m = 0; m < NB; ++m) {
+                const int i = t + m * TPL;
+                const int k = i & (P - 1);
+                const int j = (i - k) * R + k;
+#pragma unroll
+                for (int q = 0; q < R; ++q) lds.at(j + q * P) = v[m + q * NB].y;
+            }
+            exchange_sync<WAVE>();
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e].y = lds.at(t + e * TPL);
+            exchange_sync<WAVE>();
+        } else {
 #pragma unroll
         for (int m = 0; m < NB; ++m) {
             const int i = t + m * TPL;
@@ -237,6 +274,7 @@ __device__ __forceinline__ void fft_stages(cx<T> (&v)[E], const int t, const cx<
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = lds.at(t + e * TPL);
         exchange_sync<WAVE>();
+        }
         fft_stages<T, N, E, SIGN, TWS, P * R, Layout, WAVE>(v, t, tw, lds);
     }
 }

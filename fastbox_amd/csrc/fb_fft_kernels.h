@@ -57,6 +57,27 @@ enum { SMODE_PLAIN = 0, SMODE_GEN = 1, SMODE_BIN = 2, SMODE_BINF = 3 };
 // forward pass of "P(k) of apply_transfer_fn's result", leaving the filtered spectrum for the inverse.
 constexpr bool smode_bins(int mode) { return mode == SMODE_BIN || mode == SMODE_BINF; }
 
+// Half-LDS form of a strided pass (SplitTileLayout): 16 points per thread, 512-thread workgroups on the same 16-column
+// tile, real and imaginary parts exchanged one after the other through 32 KiB -- three or four workgroups per CU instead
+// of two 1024-thread ones, so that one workgroup's barrier-bound exchange phases run beside another's arithmetic.
+// FB_SPLIT_MODES: bit 0 plain, bit 1 generator, bit 2 binning / filtering passes (single precision, N = 512).
+#ifndef FB_SPLIT_MODES
+#define FB_SPLIT_MODES 0
+#endif
+#ifndef FB_SPLIT_WGS
+#define FB_SPLIT_WGS 3            // workgroups per CU the half-LDS form is compiled for (3: 80 registers per thread, 4: 64)
+#endif
+template <typename T> constexpr bool strided_split(int n, int mode, bool blk) {
+    return sizeof(T) == 4 && n == 512 && !blk &&
+           ((FB_SPLIT_MODES >> (mode == SMODE_PLAIN ? 0 : (mode == SMODE_GEN ? 1 : 2))) & 1);
+}
+template <typename T> constexpr int strided_elems_of(int n, int mode, bool blk) {
+    return strided_split<T>(n, mode, blk) ? 16 : strided_elems(n);
+}
+template <typename T> constexpr int strided_wgs_of(int n, int mode, bool blk) {
+    return strided_split<T>(n, mode, blk) ? FB_SPLIT_WGS : strided_wg_per_cu<T>(n);
+}
+
 template <typename T> struct StridedArgs {
     const cx<T>* in;
     cx<T>* out;
@@ -129,18 +150,18 @@ template <typename T> struct StridedOp {
 // offset per point where the line fits 4 GiB, shifts instead of divisions for power-of-two tile counts, the slab
 // addressing compiled only into the kernels that use it.
 template <typename T, int N, int MODE, int PERSIST, bool BLK = false>
-__global__ __launch_bounds__(tile_cols<T>(N) * (N / strided_elems(N)),
-                             fb_min(8, fb_max(1, strided_wg_per_cu<T>(N) * tile_cols<T>(N) * (N / strided_elems(N)) / 256)))
+__global__ __launch_bounds__(tile_cols<T>(N) * (N / strided_elems_of<T>(N, MODE, BLK)),
+                             fb_min(8, fb_max(1, strided_wgs_of<T>(N, MODE, BLK) * tile_cols<T>(N) * (N / strided_elems_of<T>(N, MODE, BLK)) / 256)))
 void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     static_assert(!BLK || MODE == SMODE_PLAIN, "slab addressing: plain passes only");
-    constexpr int E = strided_elems(N);
+    constexpr bool SPLIT = strided_split<T>(N, MODE, BLK);
+    constexpr int E = strided_elems_of<T>(N, MODE, BLK);
     constexpr int TPL = N / E;
     constexpr int TZ = tile_cols<T>(N);
     constexpr int NT = TZ * TPL;
     constexpr int NW = (NT + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cx<T>* tile = reinterpret_cast<cx<T>*>(smem);
-    cx<T>* twl = tile + N * TZ;
+    cx<T>* twl = reinterpret_cast<cx<T>*>(smem + (size_t)N * TZ * (SPLIT ? sizeof(T) : sizeof(cx<T>)));
     double* acc = reinterpret_cast<double*>(twl + N);          // BIN: [NW][2 nbins], whole launch
     int* lthr = reinterpret_cast<int*>(acc + (size_t)NW * 2 * (smode_bins(MODE) ? op.nbins : 0));
 
@@ -310,7 +331,8 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         const int col = bx * TZ + c;
         const bool valid = col < a.ncols;
         const long long ubase = (long long)by * a.outer_stride + bx * TZ;
-        const TileLayout<T, TZ> layf{tile, c};
+        typedef typename std::conditional<SPLIT, SplitTileLayout<T, TZ>, TileLayout<T, TZ>>::type Lay;
+        const Lay layf{reinterpret_cast<decltype(Lay::base)>(smem), c};
 
         if constexpr (MODE == SMODE_GEN) {
             // generator: thread pair j holds the modes k_x = t + j TPL (< N/2) and k_x + N/2, which share one
