@@ -1095,7 +1095,10 @@ template <typename T> struct RsdTurnArgs {
     RngKey rkey;
     int nearest;
 };
-template <int E> constexpr size_t rsd_turn_region() { return (size_t)8 * 64 * E + 4 * (64 * E + 16); }   // per wave: keys + values
+template <int E> constexpr size_t rsd_turn_region() {      // per wave: 32-bit keys + values, or the two transforms' line buffers
+    const size_t kv = (size_t)4 * 64 * E + 4 * (64 * E + 16), lb = (size_t)2 * LineLayout<float>::padded(32 * E) * 8;
+    return ((kv > lb ? kv : lb) + 15) / 16 * 16;
+}
 template <int E> constexpr size_t rsd_turn_lds() {
     return (size_t)(FB_RSDT_ZG_LDS ? 16 : 8) * 64 * E + FB_RSDT_WAVES * rsd_turn_region<E>();
 }
@@ -1105,14 +1108,14 @@ __global__ __launch_bounds__(64 * FB_RSDT_WAVES, FB_RSD_OCC) void k_rsd_turn(Rsd
     constexpr int N = 64 * E, NF = N / 2, EF = elems_per_thread(NF), TPL = NF / EF;
     constexpr int LP = LineLayout<T>::padded(NF);
     static_assert(2 * TPL <= 64 && 2 * LP * sizeof(cx<T>) <= rsd_turn_region<E>() && 2 * N * sizeof(T) <= rsd_turn_region<E>(), "layout");
-    typedef unsigned long long u64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     cx<T>* twl = reinterpret_cast<cx<T>*>(smem);                                     // [N]   shared by the block
     [[maybe_unused]] double* zgl = reinterpret_cast<double*>(smem + (size_t)8 * N);   // [N]   (FB_RSDT_ZG_LDS)
     char* mine = smem + (size_t)(FB_RSDT_ZG_LDS ? 16 : 8) * N + w * rsd_turn_region<E>();
-    u64* kex = reinterpret_cast<u64*>(mine);                                         // [N]      this wave's
-    T* vex = reinterpret_cast<T*>(mine + (size_t)8 * N);                             // [N + 16] this wave's
+    typedef typename rsd_key<T>::type key_t;
+    key_t* kex = reinterpret_cast<key_t*>(mine);                                     // [N]      this wave's
+    T* vex = reinterpret_cast<T*>(mine + sizeof(key_t) * N);                         // [N + 16] this wave's
     cx<T>* fl = reinterpret_cast<cx<T>*>(mine);        // the transforms' line buffers ([2][LP]) and
     T* rl = reinterpret_cast<T*>(mine);                // the two real lines ([2][N]) live in the same bytes, before the remap
     const double zmin = a.zgrid[0], zmax = a.zgrid[N - 1];
@@ -1168,7 +1171,7 @@ __global__ __launch_bounds__(64 * FB_RSDT_WAVES, FB_RSD_OCC) void k_rsd_turn(Rsd
     }
     rsd_wave_sync();
 #pragma unroll
-    for (int e = 0; e < E; ++e) kex[lane + 64 * e] = 0ull;
+    for (int e = 0; e < E; ++e) kex[lane + 64 * e] = 0;
     rsd_wave_sync();
     // (delta[0] + delta[N-1]) / 2: lane 0's first and lane 63's last cell
     const T d0 = __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[0]), 0));

@@ -723,7 +723,7 @@ __device__ __forceinline__ double fmod_pos(double a, double b) {
 #define FB_RSD_WAVES_SMALL 4      // lines of sight (waves) per workgroup up to 8 cells per lane (tuning: 8 with FB_RSD_OCC 6)
 #endif
 #ifndef FB_RSD_OCC
-#define FB_RSD_OCC 5              // waves per SIMD the single-precision kernel is compiled for, up to 8 cells per lane
+#define FB_RSD_OCC 6              // waves per SIMD the single-precision kernel is compiled for, up to 8 cells per lane (32-bit keys: 80 registers)
 #endif
 constexpr int rsd_waves(int E) { return E <= 8 ? FB_RSD_WAVES_SMALL : 4; }
 
@@ -735,16 +735,168 @@ __device__ __forceinline__ void rsd_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Key of a sample inside its cell: 64-bit order-preserving position bits (double-precision plans), or -- single
+// precision -- 31 bits of the in-cell fraction + 1 (0 and ~0 stay free as the "empty cell" marks).
+template <typename T> struct rsd_key { typedef unsigned long long type; };
+template <> struct rsd_key<float> { typedef unsigned int type; };
+
+// The remap of one line of sight by one wave, single-precision plans: the line in CELL units.  A sample's position is
+// s = fract((z_m - zmin - v / H) / len) (N - 1) in [0, N - 1): its cell is floor(s) (the grid is uniform) and its place
+// inside the cell a 31-bit fraction -- 4.7e-10 of a cell, three orders below what a single-precision velocity carries
+// (1e-7 of |v| / H, i.e. of a few cells).  Keys are then 32 bits: half the LDS bytes of the 64-bit position keys, the
+// 32-bit LDS atomics, 16 registers less (a sixth wave per SIMD).  A bracket's position is (cell + fraction): the
+// differences the interpolation needs are formed exactly in fp64 from the integer cell distance and the two fractions
+// (close keys cancel), the quotient in fp32.  Branch-free as the fp64 form below (see there for the phases).
+template <int E, bool ZG_GLOBAL>
+__device__ __forceinline__ void rsd_remap_line32(const float (&vin)[E], const float (&val)[E], const float* __restrict__ noise,
+                                                 const long long los, const double fill, const double* zg, unsigned int* kex,
+                                                 float* vex, const double zmin, const double len, const double Hz,
+                                                 const double sigma_nl, const RngKey rkey, const int nearest, const int lane,
+                                                 float (&y_out)[E]) {
+    constexpr int N = E * 64;
+    typedef unsigned int u32;
+    auto sw = [](int c) { return (c % E) * 64 + c / E; };
+    auto zown = [&](int e) -> double {               // this lane's e-th grid point, measured from zmin and moved up by len
+        if constexpr (ZG_GLOBAL) return (zg[lane * E + e] - zmin) + len;
+        else return zg[lane + 64 * e];
+    };
+    const double inv_Hz = 1.0 / Hz, inv_len = 1.0 / len;
+    const double cells = (double)(N - 1);
+    const double s_max = __longlong_as_double(__double_as_longlong(cells) - 1);     // largest double < N - 1
+    u32 kb[E];
+    int cell[E];
+    float nz[E];
+    if (sigma_nl > 0.0) {
+        const unsigned long long idx0 = (unsigned long long)los * N + lane * E;
+        if (noise) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) nz[e] = noise[idx0 + e];
+        } else if constexpr (E % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < E / 4; ++q)
+                stream_normals4<float>((idx0 >> 2) + q, 1u, rkey, nz[4 * q], nz[4 * q + 1], nz[4 * q + 2], nz[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) nz[e] = los_noise_at<float>(idx0 + e, rkey);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+#pragma clang fp contract(off)
+        double vel = (double)vin[e];
+        // (asm: keeps the wave-uniform case a scalar branch -- if-converted, its fp64 instructions would run for every cell)
+        if (sigma_nl > 0.0) { asm volatile(""); vel = vel + sigma_nl * (double)nz[e]; }
+        // reciprocals replace the two fp64 divisions (displacement, wrap); the wrap is a fract()
+        const double a = fma(-vel, inv_Hz, zown(e) - len);                        // z_m - zmin - vel / H
+        double sp = __builtin_amdgcn_fract(a * inv_len) * cells;                  // in [0, N - 1]
+        sp = sp < s_max ? sp : s_max;
+        const int c = (int)sp;                                                     // 0 .. N - 2
+        kb[e] = (u32)((sp - (double)c) * 2147483648.0) + 1u;                       // 1 .. 2^31
+        cell[e] = sw(c);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) atomicMax(&kex[cell[e]], kb[e]);
+    rsd_wave_sync();
+    // (the key that won a cell attaches its value: an unconditional store, the losers' to a spare slot behind the array)
+#pragma unroll
+    for (int e = 0; e < E; ++e) vex[kex[cell[e]] == kb[e] ? cell[e] : N] = val[e];
+    rsd_wave_sync();
+    unsigned occ = 0;                                 // which of this lane's cells are occupied
+    int last = -1, first = N;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool o = kex[lane + 64 * e] != 0u;
+        occ |= o ? (1u << e) : 0u;
+        first = (o && first == N) ? lane * E + e : first;
+        last = o ? lane * E + e : last;
+    }
+    int below = last, above = first;                  // inclusive scans over lanes: max from the left, min from the right
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        const int b = __shfl_up(below, sft), a = __shfl_down(above, sft);
+        if (lane >= sft) below = b > below ? b : below;
+        if (lane + sft < 64) above = a < above ? a : above;
+    }
+    int run_below = __shfl_up(below, 1);              // exclusive: lanes to the left only
+    if (lane == 0) run_below = -1;
+    int nxt_above = __shfl_down(above, 1);
+    if (lane == 63) nxt_above = N;
+    int ab[E];                                        // nearest occupied cell at or above each of this lane's cells (N: none)
+    {
+        int a = nxt_above;
+#pragma unroll
+        for (int e = E - 1; e >= 0; --e) { a = ((occ >> e) & 1u) ? lane * E + e : a; ab[e] = a; }
+    }
+    // lower bracket of every cell of this lane: (largest key, its value) of the nearest occupied cell below
+    u32 pk[E];
+    float pv[E];
+    {
+        int rb = run_below;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int q = sw(rb < 0 ? 0 : rb);
+            pk[e] = kex[q];
+            pv[e] = vex[q];
+            rb = ((occ >> e) & 1u) ? lane * E + e : rb;
+        }
+    }
+    rsd_wave_sync();
+    // second use of the arrays: per-cell minima
+#pragma unroll
+    for (int e = 0; e < E; ++e) kex[lane + 64 * e] = ~0u;
+    rsd_wave_sync();
+#pragma unroll
+    for (int e = 0; e < E; ++e) atomicMin(&kex[cell[e]], kb[e]);
+    rsd_wave_sync();
+#pragma unroll
+    for (int e = 0; e < E; ++e) vex[kex[cell[e]] == kb[e] ? cell[e] : N] = val[e];
+    rsd_wave_sync();
+    int rb = run_below;                               // cell of the lower bracket, as in the loop that fetched it
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+#pragma clang fp contract(off)
+        const int c = lane + 64 * e, own = lane * E + e;       // LDS index and number of this cell; its grid point sits at `own`
+        const bool filled = (occ >> e) & 1u;
+        // every LDS read unconditional (asm: the value counts as used, so the compiler cannot sink the read behind a per-lane
+        // branch -- exec-mask bookkeeping runs on the CU's one scalar unit), bracket indices clamped into range, the cases
+        // selected at the end
+        const int cn = ab[e] < N ? ab[e] : N - 1;
+        const int ra = sw(cn);
+        u32 cmn = kex[c], kna = kex[ra];
+        float vn = vex[ra], vc = vex[c];
+        asm volatile("" : "+v"(cmn), "+v"(kna), "+v"(vn), "+v"(vc));
+        const bool exact = filled & (cmn == 1u);                // a sample exactly on the grid point
+        const bool nofill = (rb >= 0) & (ab[e] < N);
+        const float vj = pv[e];
+        const double fj = (double)(pk[e] - 1u) * 4.656612873077392578125e-10;     // 2^-31
+        const double fn = (double)(kna - 1u) * 4.656612873077392578125e-10;
+        const double xj = (double)(own - rb) - fj;              // grid point - lower bracket, in cells (> 0)
+        const double nj = (double)(cn - rb) + (fn - fj);        // upper bracket - lower bracket
+        const float w = (float)xj * __builtin_amdgcn_rcpf((float)nj);
+        float yi = vj + (vn - vj) * w;
+        yi = (yi != yi && vj == vn) ? vj : yi;
+        float yl = nofill ? yi : (float)fill;
+        if (nearest) {                                // (wave-uniform) see k_rsd: the nearer bracket, the lower one on a midpoint
+            asm volatile("");                         // (a scalar branch, not if-converted fp64 instructions per cell)
+            const double mid = fj * 0.5 + ((double)(cn - rb) + fn) * 0.5;          // midpoint of the brackets, from the lower one's cell
+            yl = (rb < 0) ? vn : ((ab[e] >= N) ? vj : ((mid < (double)(own - rb)) ? vn : vj));
+        }
+        y_out[e] = exact ? vc : yl;
+        rb = filled ? own : rb;
+    }
+}
+
 // The remap of ONE line of sight by one wave.  On entry: vin[] / val[] = this lane's E consecutive velocities / densities
 // (cells lane E .. lane E + E - 1), zg[] = the grid in the kernel's frame and LDS order (see k_rsd_cells), kex[] zeroed,
 // all of it published to the wave; fill = (delta[0] + delta[N-1]) / 2 (np.interp outside the samples, box.py:433).
 // On exit y_out[] = the lane's E cells of the redshift-space line; kex / vex are free again.  (Shared by k_rsd_cells and
 // by the fused z pass k_rsd_turn of fb_fft_kernels.h, which must give bit-identical lines.)
-template <typename T, int E, bool ZG_GLOBAL = false>
-__device__ __forceinline__ void rsd_remap_line(const T (&vin)[E], const T (&val)[E], const T* __restrict__ noise, const long long los,
+template <typename T, int E>
+__device__ __forceinline__ void rsd_remap_line64(const T (&vin)[E], const T (&val)[E], const T* __restrict__ noise, const long long los,
                                                const double fill, const double* zg, unsigned long long* kex, T* vex,
                                                const double zmin, const double len, const double Hz, const double sigma_nl,
                                                const RngKey rkey, const int nearest, const int lane, T (&y_out)[E]) {
+    constexpr bool ZG_GLOBAL = false;
     constexpr int N = E * 64;
     typedef unsigned long long u64;
     constexpr bool SHIFTED = sizeof(T) == 4;
@@ -960,21 +1112,32 @@ __device__ __forceinline__ void rsd_remap_line(const T (&vin)[E], const T (&val)
     }
 }
 
+template <typename T, int E, bool ZG_GLOBAL = false>
+__device__ __forceinline__ void rsd_remap_line(const T (&vin)[E], const T (&val)[E], const T* __restrict__ noise, const long long los,
+                                               const double fill, const double* zg, typename rsd_key<T>::type* kex, T* vex,
+                                               const double zmin, const double len, const double Hz, const double sigma_nl,
+                                               const RngKey rkey, const int nearest, const int lane, T (&y_out)[E]) {
+    if constexpr (sizeof(T) == 4) {
+        rsd_remap_line32<E, ZG_GLOBAL>(vin, val, noise, los, fill, zg, kex, vex, zmin, len, Hz, sigma_nl, rkey, nearest, lane, y_out);
+    } else {
+        rsd_remap_line64<T, E>(vin, val, noise, los, fill, zg, kex, vex, zmin, len, Hz, sigma_nl, rkey, nearest, lane, y_out);
+    }
+}
 template <typename T, int E>
 __global__ __launch_bounds__(64 * rsd_waves(E), (sizeof(T) == 4 && E <= 8) ? FB_RSD_OCC : 1) void k_rsd_cells(
         const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise, T* __restrict__ out,
         const double* __restrict__ zgrid, double Hz, double sigma_nl, RngKey rkey, int nearest) {
     constexpr int N = E * 64;
     constexpr int FB_RSD_WAVES = rsd_waves(E);
-    typedef unsigned long long u64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    typedef typename rsd_key<T>::type key_t;
     double* zg = reinterpret_cast<double*>(smem);                                   // [N]       shared by the block
     // one key array and one value array per wave, used twice: first for the per-cell maxima (from which each
     // lane takes the brackets below its cells into registers), then again for the minima.  Half the LDS of
     // keeping both, and LDS is what limits the number of resident waves here.
-    u64* kex = reinterpret_cast<u64*>(smem) + N + w * N;                            // [N] per wave
-    T* vex = reinterpret_cast<T*>(smem + sizeof(double) * N * (1 + FB_RSD_WAVES)) + w * (N + 16);   // [N] per wave + a spare slot
+    key_t* kex = reinterpret_cast<key_t*>(smem + sizeof(double) * N) + w * N;       // [N] per wave
+    T* vex = reinterpret_cast<T*>(smem + sizeof(double) * N + sizeof(key_t) * N * FB_RSD_WAVES) + w * (N + 16);   // [N] per wave + a spare slot
     const long long los = (long long)blockIdx.x * FB_RSD_WAVES + w;                 // N*N % WAVES == 0
     const T* d = delta + los * N;
     const T* v = vz + los * N;
@@ -992,7 +1155,7 @@ __global__ __launch_bounds__(64 * rsd_waves(E), (sizeof(T) == 4 && E <= 8) ? FB_
     const double len = zmax - zmin;
     for (int m = threadIdx.x; m < N; m += 64 * FB_RSD_WAVES) zg[sw(m)] = SHIFTED ? (zgrid[m] - zmin) + len : zgrid[m];
 #pragma unroll
-    for (int e = 0; e < E; ++e) kex[lane + 64 * e] = 0ull;
+    for (int e = 0; e < E; ++e) kex[lane + 64 * e] = 0;
     __syncthreads();
     T val[E];
     // this lane's E consecutive velocities and densities in 16-byte loads (a lane's cells are contiguous)
