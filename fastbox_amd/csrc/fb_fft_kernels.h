@@ -889,8 +889,8 @@ template <typename T> struct ContigArgs {
 #ifndef FB_CONTIG_THREADS
 #define FB_CONTIG_THREADS 256      // threads per workgroup of the contiguous-axis passes (tuning: 128, 512)
 #endif
-template <int NF> constexpr int contig_lines() {   // lines per workgroup
-    return fb_max(1, FB_CONTIG_THREADS / (NF / elems_per_thread(NF)));
+template <typename T, int NF> constexpr int contig_lines() {   // lines per workgroup
+    return fb_max(1, FB_CONTIG_THREADS / (NF / elems_per_thread<T>(NF)));
 }
 
 // ---- one line of the contiguous (z) axis through the packed half-length complex transform ----------------------
@@ -901,8 +901,8 @@ template <int NF> constexpr int contig_lines() {   // lines per workgroup
 //   (Hermitian projection).  twl = W_{2 NF}^j in LDS, published before the call.
 template <typename T, int NF, bool WAVE>
 __device__ __forceinline__ void c2r_line(const cx<T>* __restrict__ in, const int packed, const int t, const cx<T>* twl,
-                                         const LineLayout<T>& lay, const T scale, cx<T> (&v)[elems_per_thread(NF)]) {
-    constexpr int E = elems_per_thread(NF), TPL = NF / E;
+                                         const LineLayout<T>& lay, const T scale, cx<T> (&v)[elems_per_thread<T>(NF)]) {
+    constexpr int E = elems_per_thread<T>(NF), TPL = NF / E;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int k = t + e * TPL;
@@ -925,9 +925,9 @@ __device__ __forceinline__ void c2r_line(const cx<T>* __restrict__ in, const int
 // r2c: v[e] = (x[2j], x[2j+1]) of a real line -> its half-spectrum row at `out` (nullptr: nothing is stored), times sc.
 //   X[k] = (Z[k] + conj Z[n-k])/2 - (i/2) W_N^k (Z[k] - conj Z[n-k])
 template <typename T, int NF, bool WAVE>
-__device__ __forceinline__ void r2c_line(cx<T> (&v)[elems_per_thread(NF)], const int t, const cx<T>* twl, const LineLayout<T>& lay,
+__device__ __forceinline__ void r2c_line(cx<T> (&v)[elems_per_thread<T>(NF)], const int t, const cx<T>* twl, const LineLayout<T>& lay,
                                          const int packed, cx<T>* __restrict__ out, const T sc) {
-    constexpr int E = elems_per_thread(NF), TPL = NF / E;
+    constexpr int E = elems_per_thread<T>(NF), TPL = NF / E;
     fft_stages<T, NF, E, -1, 2, 1, LineLayout<T>, WAVE>(v, t, twl, lay);
 #pragma unroll
     for (int e = 0; e < E; ++e) lay.at(t + e * TPL) = v[e];
@@ -957,11 +957,11 @@ __device__ __forceinline__ void r2c_line(cx<T> (&v)[elems_per_thread(NF)], const
 
 // NF = complex transform length (N for c2c, N/2 for r2c/c2r)
 template <typename T, int NF, int MODE>
-__global__ __launch_bounds__(contig_lines<NF>() * (NF / elems_per_thread(NF)))
+__global__ __launch_bounds__((contig_lines<T, NF>() * (NF / elems_per_thread<T>(NF))))
 void k_fft_contig(ContigArgs<T> a, int sign_c2c) {
-    constexpr int E = elems_per_thread(NF);
+    constexpr int E = elems_per_thread<T>(NF);
     constexpr int TPL = NF / E;
-    constexpr int LPW = contig_lines<NF>();
+    constexpr int LPW = contig_lines<T, NF>();
     constexpr int NT = LPW * TPL;
     constexpr int TWS = (MODE == ZMODE_C2C) ? 1 : 2;
     constexpr int M = NF * TWS;
@@ -1105,7 +1105,7 @@ template <int E> constexpr size_t rsd_turn_lds() {
 template <typename T, int E>
 __global__ __launch_bounds__(64 * FB_RSDT_WAVES, FB_RSD_OCC) void k_rsd_turn(RsdTurnArgs<T> a) {
     static_assert(sizeof(T) == 4 && E >= 1 && E <= 8, "single precision, 64 <= N <= 512");
-    constexpr int N = 64 * E, NF = N / 2, EF = elems_per_thread(NF), TPL = NF / EF;
+    constexpr int N = 64 * E, NF = N / 2, EF = elems_per_thread<T>(NF), TPL = NF / EF;
     constexpr int LP = LineLayout<T>::padded(NF);
     static_assert(2 * TPL <= 64 && 2 * LP * sizeof(cx<T>) <= rsd_turn_region<E>() && 2 * N * sizeof(T) <= rsd_turn_region<E>(), "layout");
     extern __shared__ __attribute__((aligned(16))) char smem[];
