@@ -22,13 +22,16 @@ cp $(ls $OUT/trace2/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 # the launches of the default command's roofline pass, every kernel alone: one box, the 64-plane batches of the two-box run
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace3 -- python3 $R/bench.py $ARGS --streams 1 --plane-batch 64 > $OUT/bench_streams1_pb64_under_rocprof.json 2> $OUT/trace3.err
 cp $(ls $OUT/trace3/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_streams1_pb64.csv
+# BASELINE config 3 (one box): the fused redshift-space z pass k_rsd_turn and the rest of that chain, every kernel alone
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace4 -- python3 $R/tools/config3_bench.py 512 > $OUT/config3_under_rocprof.txt 2> $OUT/trace4.err
+cp $(ls $OUT/trace4/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_config3.csv
 for C in FETCH_SIZE WRITE_SIZE; do
     # the default command (two boxes, 64-plane batches at 512^3): the counters are per dispatch, and the profiler runs
     # the dispatches of a counter pass one at a time
     rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS --no-one-box-pass --spin-up 0 --steps 10 --warmup 2 > /dev/null 2> $OUT/pmc_$C.err
 done
 python3 $R/tools/pmc_summary.py $OUT/pmc_fetch_write_summary.json $(ls $OUT/pmc_*/*/*counter_collection.csv) > $OUT/pmc_summary.txt
-rm -rf $OUT/trace1 $OUT/trace2 $OUT/trace3 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+rm -rf $OUT/trace1 $OUT/trace2 $OUT/trace3 $OUT/trace4 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 python3 $R/bench.py --steps 20 --warmup 5 > $OUT/bench_driver_command.json 2> $OUT/bench.err
 python3 $R/bench.py $ARGS --streams 1 > $OUT/bench_streams1.json 2>> $OUT/bench.err
 echo done

@@ -17,11 +17,13 @@ json.dump({"head": head + ("+uncommitted changes" if dirty else ""), "tag": tag,
            "kernel_stats": "%s_kernel_stats_streams1_pb64.csv" % tag,
            "kernel_stats_default_command": "%s_kernel_stats.csv" % tag,
            "kernel_stats_one_box": "%s_kernel_stats_streams1.csv" % tag,
+           "kernel_stats_config3": "%s_kernel_stats_config3.csv" % tag,
            "note": "kernel_stats: rocprofv3 --kernel-trace --stats of `bench.py --streams 1 --plane-batch 64`, i.e. the launches of "
                    "the default command's roofline pass (one box at a time, the 64-plane batches two boxes per GPU use) -- the "
                    "average that bench.py's roofline.avg_launch_us has to agree with (HIP events add ~3 us of bracket per launch); "
                    "kernel_stats_default_command: the default command itself, whose average mixes that pass with launches that "
                    "shared the chip with the other box; kernel_stats_one_box: `--streams 1` with its own 128-plane batches; "
-                   "pmc: the default command, dispatches serialised by the profiler"},
+                   "pmc: the default command, dispatches serialised by the profiler; kernel_stats_config3: tools/config3_bench.py 512 (one box, "
+                   "whole-box passes): k_rsd_turn and the other kernels of BASELINE configs[2]"},
           open(os.path.join(dst, "current.json"), "w"), indent=1)
 print("stamped", head, "dirty" if dirty else "clean")
