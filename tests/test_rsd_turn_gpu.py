@@ -82,3 +82,28 @@ def test_fused_z_pass_is_not_taken_where_it_does_not_exist():
     assert isinstance(ds, RedshiftSpaceField) and not ds.fusable()
     k, pk, err = box.binned_power_spectrum(delta_x=ds, nbins=12)
     assert np.all(np.isfinite(pk[~np.isnan(pk)])) and ds.materialised
+
+
+def test_c_entry_point_refuses_what_it_was_not_built_for():
+    """fb_power_spectrum_redshift_space: double-precision plans and grids above 512 get FB_ERR_UNSUPPORTED (the Python
+    class then runs the separate kernels), identical work spectra and a missing bin table are argument / state errors."""
+    from fastbox_amd import _lib
+    from fastbox_amd.device import HALF
+    for kw, N in ((dict(precision="f64"), 64), (dict(precision="f32"), 1024)):
+        box = _box(N, **kw)
+        eng = box.engine
+        bins, kc, thr, amb = box._bin_setup(12, None)
+        eng.set_bins(bins, thr, amb)
+        a, b = eng.empty(HALF), eng.empty(HALF)
+        with pytest.raises(_lib.FastBoxError) as err:
+            eng.power_redshift_space(a, b, 70.0, 0.0, 1, "linear")
+        assert "single-precision plan with 64 <= N <= 512" in str(err.value)
+    box = _box(64)
+    eng = box.engine
+    bins, kc, thr, amb = box._bin_setup(12, None)
+    eng.set_bins(bins, thr, amb)
+    a = eng.empty(HALF)
+    with pytest.raises(_lib.FastBoxError):
+        eng.power_redshift_space(a, a, 70.0, 0.0, 1, "linear")            # one buffer for both fields
+    with pytest.raises(_lib.FastBoxError):
+        eng.power_redshift_space(a, eng.empty(HALF), -1.0, 0.0, 1, "linear")   # H(z) <= 0
