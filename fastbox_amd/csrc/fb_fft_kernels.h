@@ -566,7 +566,11 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             }
         }
         FB_STAMP(3);
+#ifdef FB_EXPERIMENT_NOFFT     // knock-out build (tools/knockout.sh): the generator pass without its transform
+        if constexpr (MODE == SMODE_GEN) { __syncthreads(); }
+#else
         if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, layf);
+#endif
         else if constexpr (smode_bins(MODE)) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, layf);
         else {
             if (sign < 0) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, layf);
