@@ -107,3 +107,48 @@ def test_c_entry_point_refuses_what_it_was_not_built_for():
         eng.power_redshift_space(a, a, 70.0, 0.0, 1, "linear")            # one buffer for both fields
     with pytest.raises(_lib.FastBoxError):
         eng.power_redshift_space(a, eng.empty(HALF), -1.0, 0.0, 1, "linear")   # H(z) <= 0
+
+
+def test_lazy_redshift_space_field_is_an_ordinary_field_to_its_users():
+    """Whatever is done with the lazy field gives what the eager one gives: reading it (twice), arithmetic, the log-normal
+    transform, an arbitrary transfer function on its transform, a second estimate after the fused one."""
+    from fastbox_amd.box import RedshiftSpaceField
+
+    def fields(fused):
+        box = _box(64, seed=11)
+        dx = box.realise_density()
+        vz = box.to_real(box.realise_velocity()[2])
+        if not fused:
+            vz.ptr
+        return box, dx, vz, box.redshift_space_density(delta_x=dx, velocity_z=vz)
+    box, dx, vz, lazy = fields(True)
+    _, _, _, eager = fields(False)
+    assert isinstance(lazy, RedshiftSpaceField) and lazy.shape == eager.shape and lazy.dtype == eager.dtype
+    want = np.asarray(eager)
+    assert np.array_equal(np.asarray(lazy), want) and np.array_equal(np.asarray(lazy), want)
+    assert np.array_equal(np.asarray(lazy + 1.0), want.astype(np.float32) + np.float32(1.0))      # (device arithmetic: float32)
+    # the log-normal of a lazy field, and an arbitrary (host-evaluated) transfer function on its transform
+    box, dx, vz, lazy = fields(True)
+    box2, _, _, eager = fields(False)
+    a = box.binned_power_spectrum(delta_x=box.lognormal(lazy), nbins=12)
+    b = box2.binned_power_spectrum(delta_x=box2.lognormal(eager), nbins=12)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    box, dx, vz, lazy = fields(True)
+    box2, _, _, eager = fields(False)
+    tf = lambda kperp, kpar: np.exp(-0.5 * (kpar / 0.2) ** 2)
+    fa = np.asarray(box.apply_transfer_fn(box.to_k(lazy), tf))
+    fb = np.asarray(box2.apply_transfer_fn(box2.to_k(eager), tf))
+    assert np.array_equal(fa, fb)
+    # the fused estimate first, a plain one of the same field afterwards (the field is then formed the ordinary way)
+    box, dx, vz, lazy = fields(True)
+    box2, _, _, eager = fields(False)
+    first = box.binned_power_spectrum(delta_x=lazy, nbins=12)
+    assert not lazy.materialised
+    np.asarray(lazy)
+    again = box.binned_power_spectrum(delta_x=lazy, nbins=12)
+    ref = box2.binned_power_spectrum(delta_x=eager, nbins=12)
+    m = ~np.isnan(ref[1])
+    assert np.allclose(first[1][m], ref[1][m], rtol=2e-6)
+    for x, y in zip(again, ref):
+        assert np.array_equal(x, y, equal_nan=True)
