@@ -2,6 +2,8 @@
 # Tuning aid (GPU box): rebuild the library with one part of the fused generator pass knocked out at a
 # time and time the pass (tools/pass_bench.py).  Leaves the DEFAULT build in place when it finishes.
 #   bash tools/knockout.sh > gpurun_out/knockout.txt
+# Variants: KNOCKOUT_VARIANTS="... -DFB_EXPERIMENT_NOFFT ..." ('@' joins the flags of one variant); -DFB_EXPERIMENT_NOFFT
+# drops the pass's transform (profiles/r03_gen_knockout_1024_2048.txt was made with tools/build_variants.sh instead).
 set -e
 BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"
 for V in ${KNOCKOUT_VARIANTS:-"" "-DFB_EXPERIMENT_NOAMP" "-DFB_EXPERIMENT_NOBM" "-DFB_PHILOX_ROUNDS=1" \
