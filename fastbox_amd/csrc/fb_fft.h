@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace fb {
 
@@ -214,9 +215,16 @@ template <bool WAVE> __device__ __forceinline__ void exchange_sync() {
     if constexpr (WAVE) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     else __syncthreads();
 }
-template <typename T, int N, int E, int SIGN, int TWS, int P, class Layout, bool WAVE = false>
+// hook(s): called after the s-th exchange (s = 0, 1, ...), i.e. between two stages -- a place for independent work of the
+// caller (the resident generator pass trickles the previous tile's stores there)
+struct NoStageHook { template <int S> __device__ __forceinline__ void at() const {} };
+template <class F, int BASE> struct StageHook {        // calls f(integral_constant<int, BASE + s>) after the s-th exchange
+    const F& f;
+    template <int S> __device__ __forceinline__ void at() const { f(std::integral_constant<int, BASE + S>{}); }
+};
+template <typename T, int N, int E, int SIGN, int TWS, int P, class Layout, bool WAVE = false, class Hook = NoStageHook, int STAGE = 0>
 __device__ __forceinline__ void fft_stages(cx<T> (&v)[E], const int t, const cx<T>* __restrict__ tw,
-                                           const Layout& lds) {
+                                           const Layout& lds, const Hook& hook = Hook()) {
     constexpr int REM = N / P;
     constexpr int R = REM >= 8 ? 8 : REM;
     constexpr int NB = E / R;
@@ -280,7 +288,8 @@ __device__ __forceinline__ void fft_stages(cx<T> (&v)[E], const int t, const cx<
         for (int e = 0; e < E; ++e) v[e] = lds.at(t + e * TPL);
         exchange_sync<WAVE>();
         }
-        fft_stages<T, N, E, SIGN, TWS, P * R, Layout, WAVE>(v, t, tw, lds);
+        hook.template at<STAGE>();
+        fft_stages<T, N, E, SIGN, TWS, P * R, Layout, WAVE, Hook, STAGE + 1>(v, t, tw, lds, hook);
     }
 }
 

@@ -306,6 +306,36 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         bx += a.tile0;            // (0 unless the launch covers a range of tile columns)
     };
     int tile_id = blockIdx.x;
+    // Resident generator pass with room in the register file (16 points per thread: one workgroup per CU, 128 registers): the
+    // finished tile is not stored in one burst -- a CU's store path takes a tile's 128 KB only as fast as HBM drains the
+    // far-strided rows, all waves reach their stores together and wait there, and the store time ADDS to the arithmetic
+    // (profiles/r03_gen_knockout_1024_2048.txt).  The last FB_GEN_PARK rows a thread holds stay in registers instead and
+    // go out two at a time between the batches of the next tile's random numbers and between its transform's stages.
+#ifndef FB_GEN_PARK
+#define FB_GEN_PARK 16     // (2048^3: generator pass 20.4 -> 18.8 ms with all 16 rows parked, 19.5 with 8; 119 of 128 registers)
+#endif
+    constexpr int PARK = (PERSIST && MODE == SMODE_GEN && !SPLIT && E == 16) ? FB_GEN_PARK : 0;     // rows parked (0, 8 or 16)
+    constexpr int PARK0 = E - PARK;                    // first parked row
+    [[maybe_unused]] cx<T> wpark[PARK > 0 ? PARK : 1];
+    [[maybe_unused]] bool staged = false;              // wave-uniform
+    [[maybe_unused]] cx<T>* dst_prev = nullptr;
+    [[maybe_unused]] unsigned voff_prev = FB_BUF_OOB;
+    [[maybe_unused]] auto store_point = [&](cx<T>* dst, const unsigned voff, const int e, const cx<T> val) {
+        if (!a.wide) buf_store<0>(make_rsrc(dst), voff, (unsigned)e * estep_b, val);
+        else buf_store<0>(make_rsrc(dst + (long long)e * estep), voff, 0u, val);
+    };
+    // slot S of 8: parked rows [S PARK/8, (S+1) PARK/8)
+    [[maybe_unused]] auto drain = [&](auto slot_tag) {
+        constexpr int S = decltype(slot_tag)::value;
+        if constexpr (PARK > 0 && S >= 0 && S < 8) {
+            constexpr int PER = PARK / 8;
+            if (staged) {
+                asm volatile("");                      // (wave-uniform: keep it a scalar branch)
+#pragma unroll
+                for (int q = 0; q < PER; ++q) store_point(dst_prev, voff_prev, PARK0 + S * PER + q, wpark[S * PER + q]);
+            }
+        }
+    };
     // loads of tile `id` into v[] (ids past the last tile: every lane gets the out-of-range offset, which the buffer
     // range check turns into "no access" -- no branch around the loads, so the compiler's in-order vmcnt bookkeeping
     // sees the same queue on every path)
@@ -348,9 +378,10 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             // ACC = true: v += i * (those), in the lanes of column 0 only (the shared plane column).  The pass holds 64
             // VGPRs (two 1024-thread workgroups per CU): the main call forms all E modes in place in v[] with the E/2
             // Philox calls interleaved, the ACC calls go pair by pair (a second set of E temporaries would spill).
-            auto column = [&](const int kz, auto j0_tag, auto nj_tag, auto acc_tag) {
+            auto column = [&](const int kz, auto j0_tag, auto nj_tag, auto acc_tag, auto slot_tag) {
                 constexpr int J0 = decltype(j0_tag)::value, NJ = decltype(nj_tag)::value;
                 constexpr bool ACC = decltype(acc_tag)::value;
+                constexpr int SLOT = decltype(slot_tag)::value;            // >= 0: this call drains parked rows, slots SLOT and SLOT + 1
                 // (has_plane is wave-uniform: 14 of 16 tiles hold neither self-mirrored plane, and the per-lane selects of the
                 // mirror-image draws -- 30 to 40 vector instructions per thread -- are skipped there by scalar branches;
                 // the asm keeps them branches)
@@ -411,7 +442,9 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     const int gd = (flip && g > 0) ? H - g : g;
                     philox_counter(((unsigned long long)gd * N + kyd) * op.g.NZV + kz, 0u, op.key, X[j - J0]);
                 }
+                drain(std::integral_constant<int, SLOT>{});
                 philox4x32_batch<NJ>(X, op.key.k[0], op.key.k[1]);
+                drain(std::integral_constant<int, (SLOT >= 0 ? SLOT + 1 : -1)>{});
 #pragma unroll
                 for (int j = J0; j < J0 + NJ; ++j) {
                     T a0, a1, b0, b1;
@@ -503,22 +536,22 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             // (two half batches: Philox's 64-bit products are live for a whole batch, and with all E/2 calls interleaved
             // the pass does not fit its 64 VGPRs)
             if constexpr (E2 >= 4) {
-                column(col, std::integral_constant<int, 0>{}, std::integral_constant<int, E2 / 2>{}, std::false_type{});
-                column(col, std::integral_constant<int, E2 / 2>{}, std::integral_constant<int, E2 / 2>{}, std::false_type{});
+                column(col, std::integral_constant<int, 0>{}, std::integral_constant<int, E2 / 2>{}, std::false_type{}, std::integral_constant<int, 0>{});
+                column(col, std::integral_constant<int, E2 / 2>{}, std::integral_constant<int, E2 / 2>{}, std::false_type{}, std::integral_constant<int, 2>{});
             } else {
-                column(col, std::integral_constant<int, 0>{}, std::integral_constant<int, E2>{}, std::false_type{});
+                column(col, std::integral_constant<int, 0>{}, std::integral_constant<int, E2>{}, std::false_type{}, std::integral_constant<int, -1>{});
             }
             // packed, tile 0 (wave-uniform): column 0 = (k_z = 0 plane) + i (k_z = N/2 plane), both Hermitian planes
             if (pk0) {
-                column(H, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::true_type{});
-                if constexpr (E2 > 1) column(H, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::true_type{});
-                if constexpr (E2 > 2) column(H, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::true_type{});
-                if constexpr (E2 > 3) column(H, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::true_type{});
+                column(H, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::true_type{}, std::integral_constant<int, -1>{});
+                if constexpr (E2 > 1) column(H, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::true_type{}, std::integral_constant<int, -1>{});
+                if constexpr (E2 > 2) column(H, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::true_type{}, std::integral_constant<int, -1>{});
+                if constexpr (E2 > 3) column(H, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::true_type{}, std::integral_constant<int, -1>{});
                 if constexpr (E2 > 4) {
-                    column(H, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, std::true_type{});
-                    column(H, std::integral_constant<int, 5>{}, std::integral_constant<int, 1>{}, std::true_type{});
-                    column(H, std::integral_constant<int, 6>{}, std::integral_constant<int, 1>{}, std::true_type{});
-                    column(H, std::integral_constant<int, 7>{}, std::integral_constant<int, 1>{}, std::true_type{});
+                    column(H, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, std::true_type{}, std::integral_constant<int, -1>{});
+                    column(H, std::integral_constant<int, 5>{}, std::integral_constant<int, 1>{}, std::true_type{}, std::integral_constant<int, -1>{});
+                    column(H, std::integral_constant<int, 6>{}, std::integral_constant<int, 1>{}, std::true_type{}, std::integral_constant<int, -1>{});
+                    column(H, std::integral_constant<int, 7>{}, std::integral_constant<int, 1>{}, std::true_type{}, std::integral_constant<int, -1>{});
                 }
             }
             if (!valid) {
@@ -569,7 +602,11 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 #ifdef FB_EXPERIMENT_NOFFT     // knock-out build (tools/knockout.sh): the generator pass without its transform
         if constexpr (MODE == SMODE_GEN) { __syncthreads(); }
 #else
-        if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, layf);
+        if constexpr (MODE == SMODE_GEN && PARK > 0) {
+            typedef StageHook<decltype(drain), 4> StageDrain;          // slots 4, 5, 6 between the transform's stages
+            fft_stages<T, N, E, +1, 1, 1, Lay, false, StageDrain>(v, t, twl, layf, StageDrain{drain});
+            drain(std::integral_constant<int, 7>{});
+        } else if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, layf);
 #endif
         else if constexpr (smode_bins(MODE)) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, layf);
         else {
@@ -605,6 +642,13 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         if constexpr (!smode_bins(MODE) || MODE == SMODE_BINF) {
             cx<T>* dst = a.out + ((long long)by * out_outer + bx * TZ) + tbase_o;
             const unsigned voff = (valid && !a.drop_io) ? loff_o : FB_BUF_OOB;
+            if constexpr (PARK > 0) {
+#pragma unroll
+                for (int e = 0; e < PARK0; ++e) store_point(dst, voff, e, cscale(v[e], a.scale));
+#pragma unroll
+                for (int e = 0; e < PARK; ++e) wpark[e] = cscale(v[PARK0 + e], a.scale);
+                dst_prev = dst; voff_prev = voff; staged = true;
+            } else
             store_rows(dst, voff, v, a.scale);
             // resident workgroup, plain pass: the next tile's loads go out right behind the stores (a store has read its
             // registers when it issues), so its memory latency runs beside this tile's store drain
@@ -767,6 +811,12 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         if constexpr (!PERSIST) break;
         tile_id += gridDim.x;
     } while (tile_id < a.ntiles);
+    if constexpr (PARK > 0) {
+        if (staged) {
+#pragma unroll
+            for (int e = 0; e < PARK; ++e) store_point(dst_prev, voff_prev, PARK0 + e, wpark[e]);
+        }
+    }
     if constexpr (smode_bins(MODE)) {
 #ifdef FB_STAMPS
         if ((tid & 63) == 0 && stamp_ok) stamp[8 + (tid >> 6)] = (long long)__builtin_amdgcn_s_memtime();   // this wave's binning is done

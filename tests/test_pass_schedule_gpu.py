@@ -40,6 +40,27 @@ def test_resident_schedule_equals_one_tile_per_workgroup(N, precision):
             assert np.allclose(a[2][m], b[2][m], rtol=1e-9, atol=1e-12 * b[1][m].max()), sched
 
 
+def test_generator_with_parked_stores_at_2048():
+    """N = 2048 (16 points per thread): the resident generator pass keeps its finished tile in registers and stores it two
+    rows at a time between the next tile's batches and stages.  Against one workgroup per tile, which stores at once:
+    sum, sum of squares and maximum of delta_x (fixed-order device reductions) equal bit for bit, P(k) to fp64 rounding."""
+    from fastbox_amd import CosmoBox, default_cosmo
+    out = []
+    for sched in ((0, 0, 0), (-1, -1, -1)):
+        box = CosmoBox(cosmo=default_cosmo, box_scale=2e3, nsamp=2048, realise_now=False, precision="f32", rng="device", seed=23)
+        box.engine.set_pass_schedule(*sched)
+        dx = box.realise_density()
+        pk = box.binned_power_spectrum(delta_x=dx, nbins=20)
+        eng = box.engine
+        out.append((eng.sum_real(dx), eng.sum_real(dx, squared=True), eng.max_real(dx), pk))
+        del dx
+        eng.close()
+    a, b = out
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+    m = ~np.isnan(a[3][1])
+    assert np.array_equal(a[3][0], b[3][0]) and np.allclose(a[3][1][m], b[3][1][m], rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("P", [1, 2, 8])
 def test_resident_schedule_in_the_slab_path(P):
     """The exchange-buffer addressing of the slab-decomposed transform (a line cut into per-rank pieces) under the
