@@ -339,15 +339,29 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
     // loads of tile `id` into v[] (ids past the last tile: every lane gets the out-of-range offset, which the buffer
     // range check turns into "no access" -- no branch around the loads, so the compiler's in-order vmcnt bookkeeping
     // sees the same queue on every path)
+    // Resident binning pass with room in the register file (16 points per thread: one workgroup per CU, 128 registers): a
+    // second register set takes the NEXT tile's loads at the very start of a tile, so that they have the whole tile time to
+    // arrive instead of the last 40 % of it (FB_BIN_DBUF).
+#ifndef FB_BIN_DBUF
+#define FB_BIN_DBUF 1        // (2048^3: binning pass 12.67 -> 12.40 ms; 122 of 128 registers)
+#endif
+    constexpr bool DBUF = PERSIST && MODE == SMODE_BIN && !SPLIT && E == 16 && FB_BIN_DBUF;
+    [[maybe_unused]] cx<T> vnext[DBUF ? E : 1];
     [[maybe_unused]] auto load_tile = [&](int id) {
         int lbx, lby;
         place(id, lbx, lby);
         const cx<T>* src = a.in + ((long long)lby * a.outer_stride + lbx * TZ + tbase);
         const unsigned voff = (id < a.ntiles && lbx * TZ + c < a.ncols && !a.drop_io) ? loff : FB_BUF_OOB;
-        load_rows(v, src, voff);
+        if constexpr (DBUF) load_rows(vnext, src, voff);
+        else load_rows(v, src, voff);
     };
     if constexpr (MODE != SMODE_GEN && PERSIST) load_tile(tile_id);     // the launcher guarantees gridDim.x <= ntiles
     do {    // PERSIST: tiles blockIdx.x, blockIdx.x + gridDim.x, ...; otherwise exactly one tile
+        if constexpr (DBUF) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = vnext[e];
+            load_tile(tile_id + (int)gridDim.x);
+        }
         // Resident form: everything a tile derives from the lane's coordinates (LDS addresses of every stage, mode
         // numbers, row pointers: dozens of values) is loop-invariant, and hoisted out of the tile loop it would stay
         // live across it -- 10 to 90 registers spilled, and reloads from scratch that queue behind the next tile's
@@ -671,7 +685,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             for (int e = 0; e < E; ++e) ptile[(t + e * TPL) * TZ + c] = pq[e];
             // resident workgroup: v[] is free from here on -- the next tile's loads are issued now and the binning below
             // runs under their latency
-            if constexpr (PERSIST) load_tile(tile_id + (int)gridDim.x);
+            if constexpr (PERSIST && !DBUF) load_tile(tile_id + (int)gridDim.x);
             __syncthreads();
             FB_STAMP(5);
             double* row = acc + (size_t)(tid >> 6) * 2 * nb;
