@@ -24,7 +24,9 @@ Prints ONE JSON line (see README / DESIGN.md for the fields).  Besides the contr
                      after the timed region ("timed_in" says which)
   pipeline_roofline  whole step against 8 TB/s, on SURVEY 8(d)'s model bytes and on the bytes actually moved
   f64                the same step on a precision='f64' plan (the reference computes in complex128)
-  config3            BASELINE configs[2]: gen -> v_z -> redshift space -> wedge filter -> P(k) + filtered field
+  config3            BASELINE configs[2]: gen -> v_z -> redshift space -> wedge filter -> P(k) + filtered field, independent
+                     chains on --streams boxes as the headline's realisations (+ one_box, + the remap kernel's own roofline)
+  roofline_gen/_bin/_z  the fused generator, binning and z passes, un-overlapped (HIP events on one stream)
   sizes              N = 1: the same step at 256^3, 1024^3, 2048^3 on this GPU
   strong_scaling     N > 1: ONE box over all ranks (slab-decomposed FFT, RCCL all-to-all) at 1024^3 and 2048^3,
                      run as child jobs of rank 0 after the replicas leg (a failure there cannot take the line down)
