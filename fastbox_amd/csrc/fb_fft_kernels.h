@@ -71,11 +71,27 @@ template <typename T> constexpr bool strided_split(int n, int mode, bool blk) {
     return sizeof(T) == 4 && n == 512 && !blk &&
            ((FB_SPLIT_MODES >> (mode == SMODE_PLAIN ? 0 : (mode == SMODE_GEN ? 1 : 2))) & 1);
 }
+// The generator pass of a 1024-point line in single precision takes the 2048 shape -- 16 points per thread, a 16-column
+// (128-byte row) tile of 128 KiB, one resident workgroup per CU -- because only that shape has the registers to keep the
+// finished tile while the next one is drawn (FB_GEN_PARK below): the pass is its arithmetic PLUS its store time otherwise
+// (profiles/r03_gen_knockout_1024_2048.txt).  FB_GEN_WIDE_FROM: smallest such N (tuning; 1 << 30: off).
+#ifndef FB_GEN_WIDE_FROM
+#define FB_GEN_WIDE_FROM 1024       // (1024^3: generator pass 2.17 -> 1.90 ms, 114.6 -> 117 boxes/s)
+#endif
+template <typename T> constexpr bool strided_wide(int n, int mode, bool blk) {
+    return sizeof(T) == 4 && mode == SMODE_GEN && !blk && n >= (FB_GEN_WIDE_FROM) && n >= 1024 && n < FB_E16_FROM;
+}
 template <typename T> constexpr int strided_elems_of(int n, int mode, bool blk) {
-    return strided_split<T>(n, mode, blk) ? 16 : strided_elems(n);
+    return (strided_split<T>(n, mode, blk) || strided_wide<T>(n, mode, blk)) ? 16 : strided_elems(n);
+}
+template <typename T> constexpr int tile_cols_of(int n, int mode, bool blk) {
+#ifndef FB_GEN_WIDE_COLS
+#define FB_GEN_WIDE_COLS 16        // (tuning: 8 = a 64 KiB tile, 512 threads, two workgroups per CU)
+#endif
+    return strided_wide<T>(n, mode, blk) ? fb_min(FB_GEN_WIDE_COLS, 131072 / (n * 2 * (int)sizeof(T))) : tile_cols<T>(n);
 }
 template <typename T> constexpr int strided_wgs_of(int n, int mode, bool blk) {
-    return strided_split<T>(n, mode, blk) ? FB_SPLIT_WGS : strided_wg_per_cu<T>(n);
+    return strided_split<T>(n, mode, blk) ? FB_SPLIT_WGS : (strided_wide<T>(n, mode, blk) ? (FB_GEN_WIDE_COLS <= 8 ? 2 : 1) : strided_wg_per_cu<T>(n));
 }
 
 template <typename T> struct StridedArgs {
@@ -150,14 +166,15 @@ template <typename T> struct StridedOp {
 // offset per point where the line fits 4 GiB, shifts instead of divisions for power-of-two tile counts, the slab
 // addressing compiled only into the kernels that use it.
 template <typename T, int N, int MODE, int PERSIST, bool BLK = false>
-__global__ __launch_bounds__(tile_cols<T>(N) * (N / strided_elems_of<T>(N, MODE, BLK)),
-                             fb_min(8, fb_max(1, strided_wgs_of<T>(N, MODE, BLK) * tile_cols<T>(N) * (N / strided_elems_of<T>(N, MODE, BLK)) / 256)))
+__global__ __launch_bounds__((tile_cols_of<T>(N, MODE, BLK) * (N / strided_elems_of<T>(N, MODE, BLK))),
+                             fb_min(8, fb_max(1, strided_wgs_of<T>(N, MODE, BLK) * tile_cols_of<T>(N, MODE, BLK) * (N / strided_elems_of<T>(N, MODE, BLK)) / 256)))
 void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
-    static_assert(!BLK || MODE == SMODE_PLAIN, "slab addressing: plain passes only");
+    static_assert(!BLK || MODE == SMODE_PLAIN || MODE == SMODE_GEN, "slab addressing: plain passes (and the generator pass of a k_z chunk, which\n"
+                  "keeps the narrow tile the chunk bounds are counted in)");
     constexpr bool SPLIT = strided_split<T>(N, MODE, BLK);
     constexpr int E = strided_elems_of<T>(N, MODE, BLK);
     constexpr int TPL = N / E;
-    constexpr int TZ = tile_cols<T>(N);
+    constexpr int TZ = tile_cols_of<T>(N, MODE, BLK);
     constexpr int NT = TZ * TPL;
     constexpr int NW = (NT + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
