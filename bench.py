@@ -350,11 +350,18 @@ def config3_leg(args, N, rank, local_rank, torch, chains=30):
         _check_finite(out, "config3")
         return dt
     try:
-        dt = timed(boxes, chains)
+        # (the two configurations alternately, twice: the first timed region of a leg still sees the clocks settle)
         one = boxes[:1]
-        if len(boxes) > 1:
-            boxes[0].engine.set_plane_batching(-1, 0)           # alone on the GPU: the library's own batching
-        dt_one = timed(one, chains) if len(boxes) > 1 else dt
+        shared = getattr(boxes[0], "_bench_plane_batching", (-1, 0))
+        dts, dts_one = [], []
+        for _ in range(2):
+            boxes[0].engine.set_plane_batching(*shared)
+            dts.append(timed(boxes, chains))
+            if len(boxes) > 1:
+                boxes[0].engine.set_plane_batching(-1, 0)       # alone on the GPU: the library's own batching
+                dts_one.append(timed(one, chains))
+        dt = min(dts)
+        dt_one = min(dts_one) if dts_one else dt
         # the remap kernel alone, un-overlapped: HIP events around every launch of its class
         eng = boxes[0].engine
         eng.profile_start(["rsd"], stride=1)
