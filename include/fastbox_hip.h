@@ -354,7 +354,7 @@ int fb_slab_x_bin_chunk(fb_plan* plan, void* kchunk, int nparts, int part, int t
 int fb_set_plane_batching(fb_plan* plan, int planes, int streams);
 /* How the strided FFT passes (x, y) of this plan are scheduled, per class (plain pass, fused generator pass, fused
  * binning pass): 0 = one workgroup per tile, 1 = resident workgroups that walk the tiles and load their next tile
- * while finishing the current one, -1 (default) = by grid size (resident where a CU holds one workgroup of the pass: N = 2048).  The transforms are bit-identical in both forms; the binning pass groups its fp64
+ * while finishing the current one, -1 (default) = by grid size (resident where a CU holds one workgroup of the pass: N = 2048, and the generator pass from N = 1024).  The transforms are bit-identical in both forms; the binning pass groups its fp64
  * partial sums by resident workgroup instead of by tile (differences at the 1e-16 level).  Grids below 256^3 always use 0. */
 int fb_set_pass_schedule(fb_plan* plan, int plain, int generator, int binning);
 /* Fused log-normal transforms (pre_exp of fb_fft_r2c / fb_power_spectrum_device / _pending) form exp(x - shift).  The
