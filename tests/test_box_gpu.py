@@ -43,6 +43,24 @@ def _field_close(a, b, tol):
     return np.max(np.abs(a - b)) <= tol * scale
 
 
+def _pk_dev(got, want):
+    """largest relative deviation of (pk,) or (pk, stddev) from the expected arrays (stddev against |stddev| + |pk|: the
+    reference's std is exactly 0 for single-valued bins) -- for assertion messages"""
+    pk_ref = np.asarray(want[0])
+    worst = []
+    for n, (a, b) in enumerate(zip(got, want)):
+        a, b = np.asarray(a), np.asarray(b)
+        m = ~np.isnan(b)
+        den = np.abs(b[m]) + (0 if n == 0 else np.abs(pk_ref[m]))
+        worst.append(float(np.max(np.abs(a[m] - b[m]) / den)) if m.any() else 0.0)
+    return worst
+
+
+def _field_dev(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b)) / np.sqrt(np.mean(np.abs(b) ** 2)))
+
+
 def _pk_close(got, want, tol):
     """got/want = (pk,) or (pk, stddev).  pk: relative.  stddev: relative, with an absolute
     floor of tol * pk (the reference's std is exactly 0 for single-valued bins)."""
@@ -113,10 +131,14 @@ def test_derived_fields(golden_dir, name, precision):
     box = _box(g, precision)
     dx = box.realise_density()
 
+    # log-normal field and its P(k) against the reference's own: north_star's 1e-5 on P(k) holds for the single-precision plan
+    # too (measured, tools/lognormal_dev.py, profiles/r04_lognormal_dev.txt: 1.7e-7 ... 2.4e-6 over the golden cases, sigma up to
+    # 8.1); the field itself carries exp()'s amplification of delta's rounding (|d delta| ~ 6e-7 sigma), hence 2 * ftol
     ln = box.lognormal(dx)
-    assert _field_close(p(ln), g["lognormal"], 5 * ftol)
+    assert _field_close(p(ln), g["lognormal"], 2 * ftol), "log-normal field off by %.3e rms" % _field_dev(p(ln), g["lognormal"])
     kc, pk, err = box.binned_power_spectrum(delta_x=ln)
-    assert _pk_close((pk, err), (g["pkln_p"], g["pkln_e"]), 3 * ptol)
+    assert _pk_close((pk, err), (g["pkln_p"], g["pkln_e"]), ptol), \
+        "log-normal P(k), stddev off by %r (tolerance %g)" % (_pk_dev((pk, err), (g["pkln_p"], g["pkln_e"])), ptol)
 
     # transfer functions: generic callable (host-evaluated table) and on-device parametric form
     for fn in (standin.beam_highpass, BeamHighpass(kpar0=0.001, kperp0=0.1, power=2.)):
@@ -575,7 +597,9 @@ def test_headline_size_against_the_reference(golden_dir, precision):
     kc, pk, err = box.binned_power_spectrum(kbins=g["kbins"])
     assert _pk_close((pk, err), (g["pkkb_p"], g["pkkb_e"]), ptol)
     ln = box.lognormal(dx)
-    assert _field_close(np.asarray(ln[::s, ::s, ::s]), g["lognormal"], 5 * ftol)
+    lsub = np.asarray(ln[::s, ::s, ::s])
+    assert _field_close(lsub, g["lognormal"], 2 * ftol), "log-normal field off by %.3e rms" % _field_dev(lsub, g["lognormal"])
     kc, pk, err = box.binned_power_spectrum(delta_x=ln)
     assert np.array_equal(kc, g["pkln_k"])
-    assert _pk_close((pk, err), (g["pkln_p"], g["pkln_e"]), 3 * ptol)
+    assert _pk_close((pk, err), (g["pkln_p"], g["pkln_e"]), ptol), \
+        "log-normal P(k), stddev off by %r (tolerance %g)" % (_pk_dev((pk, err), (g["pkln_p"], g["pkln_e"])), ptol)
