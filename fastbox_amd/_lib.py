@@ -101,6 +101,7 @@ SIGNATURES = {
     "fb_slab_x_bin_chunk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fb_set_plane_batching": (c_int, [c_void_p, c_int, c_int]),
     "fb_set_pass_schedule": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "fb_set_tile_rows": (c_int, [c_void_p, c_int]),
     "fb_set_exp_shift": (c_int, [c_void_p, ctypes.c_double]),
     "fb_debug_strided_pass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fb_debug_read_stamps": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), c_i64]),

@@ -736,6 +736,12 @@ int fb_set_pass_schedule(fb_plan* p, int plain, int generator, int binning) {
     p->pass_schedule[0] = plain; p->pass_schedule[1] = generator; p->pass_schedule[2] = binning;
     return FB_OK;
 }
+int fb_set_tile_rows(fb_plan* p, int bytes) {
+    FB_REQUIRE(p, "null pointer");
+    FB_REQUIRE(bytes == 0 || bytes == 64 || bytes == 128, "row segment of the strided passes' tiles: 0 (default), 64 or 128 bytes");
+    p->wide_rows = bytes == 0 ? -1 : (bytes == 64 ? 0 : 7);
+    return FB_OK;
+}
 int fb_set_exp_shift(fb_plan* p, double shift) {
     FB_REQUIRE(p, "null pointer");
     FB_REQUIRE(shift == shift && shift > -1e4 && shift < 1e4, "shift out of range");

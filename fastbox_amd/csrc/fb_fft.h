@@ -191,10 +191,16 @@ template <typename T, int TZ> struct TileLayout {
 };
 // The same tile at half the LDS: real parts and imaginary parts go through it one after the other (a thread keeps the
 // half that is not on its way in registers), so that a CU holds twice as many tiles -- or workgroups half the size.
-template <typename T, int TZ> struct SplitTileLayout {
+// SW (16 four-byte columns: a row is 64 bytes, HALF of the 32 banks a 32-lane group of ds_read/write_b32 spans): rows whose
+// positions differ by a multiple of 8 -- the first stage's scattered writes -- would all land in the same half; exchanging the two
+// halves of every row pair by bit 3 of the position makes a lane group's two rows hit different halves in every stage.
+template <typename T, int TZ, bool SW = false> struct SplitTileLayout {
     static constexpr bool split = true;
     T* base; int col;
-    __device__ __forceinline__ T& at(int pos) const { return base[pos * TZ + col]; }
+    __device__ __forceinline__ T& at(int pos) const {
+        if constexpr (SW) return base[(pos * TZ + col) ^ (((pos >> 3) & 1) * TZ)];
+        else return base[pos * TZ + col];
+    }
 };
 // Contiguous-axis passes: one line per thread group, one pad element every 8
 // so that the radix-8 first-stage scatter (lane stride 8 elements) spreads

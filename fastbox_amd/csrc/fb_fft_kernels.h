@@ -67,9 +67,26 @@ constexpr bool smode_bins(int mode) { return mode == SMODE_BIN || mode == SMODE_
 #ifndef FB_SPLIT_WGS
 #define FB_SPLIT_WGS 3            // workgroups per CU the half-LDS form is compiled for (3: 80 registers per thread, 4: 64)
 #endif
+// N = 2048, single precision: the full-complex tile holds 2048 rows x 8 columns (64-byte row segments), and 64-byte segments cap
+// the far-strided passes at 3.4-4.3 TB/s where 128-byte rows read at 6.2 and copy at 5.2-5.3 (tools/stride_copy_2048.hip,
+// profiles/r04_stride_copy_2048.txt).  2048 rows x 16 columns fit the LDS as REAL values (128 KiB): the half-LDS exchange with 32
+// points per thread, 1024 threads, one resident workgroup per CU (4 waves per SIMD: 128 registers).
+// FB_ROW128_MODES: bit 0 plain, bit 1 generator, bit 2 binning pass.
+#ifndef FB_ROW128_MODES
+#define FB_ROW128_MODES 7
+#endif
+#ifndef FB_ROW128_SWIZZLE
+#define FB_ROW128_SWIZZLE 0     // 1: SplitTileLayout's bank swizzle (removes the first stage's two-way write conflicts; its XOR keeps the
+                                // compiler from folding the exchange addresses into immediates: more registers)
+#endif
+template <typename T> constexpr bool strided_row128(int n, int mode, bool blk) {
+    return sizeof(T) == 4 && n == 2048 && !blk && mode != SMODE_BINF &&
+           ((FB_ROW128_MODES >> (mode == SMODE_PLAIN ? 0 : (mode == SMODE_GEN ? 1 : 2))) & 1);
+}
 template <typename T> constexpr bool strided_split(int n, int mode, bool blk) {
-    return sizeof(T) == 4 && n == 512 && !blk &&
-           ((FB_SPLIT_MODES >> (mode == SMODE_PLAIN ? 0 : (mode == SMODE_GEN ? 1 : 2))) & 1);
+    return strided_row128<T>(n, mode, blk) ||
+           (sizeof(T) == 4 && n == 512 && !blk &&
+            ((FB_SPLIT_MODES >> (mode == SMODE_PLAIN ? 0 : (mode == SMODE_GEN ? 1 : 2))) & 1));
 }
 // The generator pass of a 1024-point line in single precision takes the 2048 shape -- 16 points per thread, a 16-column
 // (128-byte row) tile of 128 KiB, one resident workgroup per CU -- because only that shape has the registers to keep the
@@ -82,16 +99,16 @@ template <typename T> constexpr bool strided_wide(int n, int mode, bool blk) {
     return sizeof(T) == 4 && mode == SMODE_GEN && !blk && n >= (FB_GEN_WIDE_FROM) && n >= 1024 && n < FB_E16_FROM;
 }
 template <typename T> constexpr int strided_elems_of(int n, int mode, bool blk) {
-    return (strided_split<T>(n, mode, blk) || strided_wide<T>(n, mode, blk)) ? 16 : strided_elems(n);
+    return strided_row128<T>(n, mode, blk) ? 32 : ((strided_split<T>(n, mode, blk) || strided_wide<T>(n, mode, blk)) ? 16 : strided_elems(n));
 }
 template <typename T> constexpr int tile_cols_of(int n, int mode, bool blk) {
 #ifndef FB_GEN_WIDE_COLS
 #define FB_GEN_WIDE_COLS 16        // (tuning: 8 = a 64 KiB tile, 512 threads, two workgroups per CU)
 #endif
-    return strided_wide<T>(n, mode, blk) ? fb_min(FB_GEN_WIDE_COLS, 131072 / (n * 2 * (int)sizeof(T))) : tile_cols<T>(n);
+    return strided_row128<T>(n, mode, blk) ? 16 : (strided_wide<T>(n, mode, blk) ? fb_min(FB_GEN_WIDE_COLS, 131072 / (n * 2 * (int)sizeof(T))) : tile_cols<T>(n));
 }
 template <typename T> constexpr int strided_wgs_of(int n, int mode, bool blk) {
-    return strided_split<T>(n, mode, blk) ? FB_SPLIT_WGS : (strided_wide<T>(n, mode, blk) ? (FB_GEN_WIDE_COLS <= 8 ? 2 : 1) : strided_wg_per_cu<T>(n));
+    return strided_row128<T>(n, mode, blk) ? 1 : (strided_split<T>(n, mode, blk) ? FB_SPLIT_WGS : (strided_wide<T>(n, mode, blk) ? (FB_GEN_WIDE_COLS <= 8 ? 2 : 1) : strided_wg_per_cu<T>(n)));
 }
 
 template <typename T> struct StridedArgs {
@@ -165,12 +182,15 @@ template <typename T> struct StridedOp {
 // the pass was bound by its scalar unit, not by its butterflies).  Hence: one descriptor per tile and a 32-bit scalar
 // offset per point where the line fits 4 GiB, shifts instead of divisions for power-of-two tile counts, the slab
 // addressing compiled only into the kernels that use it.
-template <typename T, int N, int MODE, int PERSIST, bool BLK = false>
+// CSIGN (plain passes): +1 / -1 = the direction is a compile-time constant, 0 = the `sign` argument decides.  With both
+// directions in one kernel the compiler keeps state of both instantiations live across the branch: the 32-point form needs
+// 95 registers more than its 128 and spills every tile's loads to scratch; with one direction it takes 113 and spills nothing.
+template <typename T, int N, int MODE, int PERSIST, bool BLK = false, int CSIGN = 0>
 __global__ __launch_bounds__((tile_cols_of<T>(N, MODE, BLK) * (N / strided_elems_of<T>(N, MODE, BLK))),
                              fb_min(8, fb_max(1, strided_wgs_of<T>(N, MODE, BLK) * tile_cols_of<T>(N, MODE, BLK) * (N / strided_elems_of<T>(N, MODE, BLK)) / 256)))
 void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
-    static_assert(!BLK || MODE == SMODE_PLAIN || MODE == SMODE_GEN, "slab addressing: plain passes (and the generator pass of a k_z chunk, which\n"
-                  "keeps the narrow tile the chunk bounds are counted in)");
+    static_assert(!BLK || MODE == SMODE_PLAIN || MODE == SMODE_GEN || MODE == SMODE_BIN, "slab addressing: plain passes (and the generator / binning\n"
+                  "pass of a k_z chunk, which keep the narrow tile the chunk bounds are counted in)");
     constexpr bool SPLIT = strided_split<T>(N, MODE, BLK);
     constexpr int E = strided_elems_of<T>(N, MODE, BLK);
     constexpr int TPL = N / E;
@@ -392,7 +412,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         const int col = bx * TZ + c;
         const bool valid = col < a.ncols;
         const long long ubase = (long long)by * a.outer_stride + bx * TZ;
-        typedef typename std::conditional<SPLIT, SplitTileLayout<T, TZ>, TileLayout<T, TZ>>::type Lay;
+        typedef typename std::conditional<SPLIT, SplitTileLayout<T, TZ, (FB_ROW128_SWIZZLE && strided_row128<T>(N, MODE, BLK))>, TileLayout<T, TZ>>::type Lay;
         const Lay layf{reinterpret_cast<decltype(Lay::base)>(smem), c};
 
         if constexpr (MODE == SMODE_GEN) {
@@ -566,7 +586,22 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
             };
             // (two half batches: Philox's 64-bit products are live for a whole batch, and with all E/2 calls interleaved
             // the pass does not fit its 64 VGPRs)
-            if constexpr (E2 >= 4) {
+            if constexpr (E2 >= 16) {
+                // 32 points per thread (128-byte rows at N = 2048): batches of FB_ROW128_GEN_BATCH calls, so that a batch's
+                // counters, products and amplitudes fit beside the 64 registers of v[]
+#ifndef FB_ROW128_GEN_BATCH
+#define FB_ROW128_GEN_BATCH 2
+#endif
+                constexpr int GB = FB_ROW128_GEN_BATCH;
+                auto batches = [&](auto self, auto j_tag) {
+                    constexpr int J = decltype(j_tag)::value;
+                    if constexpr (J < E2) {
+                        column(col, std::integral_constant<int, J>{}, std::integral_constant<int, GB>{}, std::false_type{}, std::integral_constant<int, -1>{});
+                        self(self, std::integral_constant<int, J + GB>{});
+                    }
+                };
+                batches(batches, std::integral_constant<int, 0>{});
+            } else if constexpr (E2 >= 4) {
                 column(col, std::integral_constant<int, 0>{}, std::integral_constant<int, E2 / 2>{}, std::false_type{}, std::integral_constant<int, 0>{});
                 column(col, std::integral_constant<int, E2 / 2>{}, std::integral_constant<int, E2 / 2>{}, std::false_type{}, std::integral_constant<int, 2>{});
             } else {
@@ -583,6 +618,16 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
                     column(H, std::integral_constant<int, 5>{}, std::integral_constant<int, 1>{}, std::true_type{}, std::integral_constant<int, -1>{});
                     column(H, std::integral_constant<int, 6>{}, std::integral_constant<int, 1>{}, std::true_type{}, std::integral_constant<int, -1>{});
                     column(H, std::integral_constant<int, 7>{}, std::integral_constant<int, 1>{}, std::true_type{}, std::integral_constant<int, -1>{});
+                }
+                if constexpr (E2 > 8) {      // pairs 8 .. E2 - 1, one by one as above
+                    auto rest = [&](auto self, auto j_tag) {
+                        constexpr int J = decltype(j_tag)::value;
+                        if constexpr (J < E2) {
+                            column(H, std::integral_constant<int, J>{}, std::integral_constant<int, 1>{}, std::true_type{}, std::integral_constant<int, -1>{});
+                            self(self, std::integral_constant<int, J + 1>{});
+                        }
+                    };
+                    rest(rest, std::integral_constant<int, 8>{});
                 }
             }
             if (!valid) {
@@ -640,6 +685,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
         } else if constexpr (MODE == SMODE_GEN) fft_stages<T, N, E, +1, 1, 1>(v, t, twl, layf);
 #endif
         else if constexpr (smode_bins(MODE)) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, layf);
+        else if constexpr (CSIGN != 0) fft_stages<T, N, E, CSIGN, 1, 1>(v, t, twl, layf);
         else {
             if (sign < 0) fft_stages<T, N, E, -1, 1, 1>(v, t, twl, layf);
             else          fft_stages<T, N, E, +1, 1, 1>(v, t, twl, layf);

@@ -20,6 +20,8 @@ struct fb_plan {
     int debug_no_mem = 0;    // tuning aid (fb_debug_strided_pass mode >= 10)
     int pass_schedule[3] = {-1, -1, -1};   // per strided-pass class (plain, generator, binning): 0 one workgroup per tile,
                                            // 1 resident workgroups walking the tiles, -1 by grid size (fb_set_pass_schedule)
+    int wide_rows = -1;      // strided passes at N = 2048, single precision: bit mask of the pass classes (1 plain, 2 generator, 4 binning)
+                             // that run in 128-byte rows; -1: the library's choice (fb_set_tile_rows; FB_WIDE_ROWS=<mask> overrides it)
     int plane_batch = -1;    // x-planes per batch of the y/z passes: -1 sized to the Infinity Cache, 0 whole box (fb_set_plane_batching)
     int plane_streams = 0;   // 1 | 2 streams for alternate batches; 0: by grid size
     double exp_shift = 0.0;  // fused log-normal transforms use exp(x - exp_shift) (fb_set_exp_shift)

@@ -291,6 +291,10 @@ class Engine(object):
         per class of strided FFT pass."""
         _lib.call("fb_set_pass_schedule", self._plan, int(plain), int(generator), int(binning))
 
+    def set_tile_rows(self, nbytes=0):
+        """Row segment of the strided passes' tiles at N = 2048 (single precision): 128 (default, 0) or 64 bytes."""
+        _lib.call("fb_set_tile_rows", self._plan, int(nbytes))
+
     def upload(self, arr, kind):
         """Host ndarray (N,N,N) -> device.  kind REAL or FULL."""
         N = self.N
@@ -318,6 +322,16 @@ class Engine(object):
         h = np.empty((N, N, N), dtype=dt)
         _lib.call("fb_memcpy_d2h", _ptr(h), d.ptr, h.nbytes, self.stream)
         return h.astype(np.float64 if d.kind == REAL else np.complex128)
+
+    def download_plane(self, d, ix):
+        """One x-plane of a real device field as a host array in the plan's precision (no copy of the whole box)."""
+        N = self.N
+        if d.kind != REAL or not 0 <= ix < N:
+            raise ValueError("download_plane: a real field and 0 <= ix < N")
+        h = np.empty((N, N), dtype=self.rdtype)
+        _lib.call("fb_memcpy_d2h", _ptr(h), d.ptr + ix * h.nbytes, h.nbytes, self.stream)
+        _lib.call("fb_stream_sync", self.stream)
+        return h
 
     def download_half_raw(self, d):
         """Half spectrum as stored, (N, N, pitch) complex; columns >= N/2+1 are padding."""

@@ -357,6 +357,13 @@ int fb_set_plane_batching(fb_plan* plan, int planes, int streams);
  * while finishing the current one, -1 (default) = by grid size (resident where a CU holds one workgroup of the pass: N = 2048, and the generator pass from N = 1024).  The transforms are bit-identical in both forms; the binning pass groups its fp64
  * partial sums by resident workgroup instead of by tile (differences at the 1e-16 level).  Grids below 256^3 always use 0. */
 int fb_set_pass_schedule(fb_plan* plan, int plain, int generator, int binning);
+/* Row segment of the strided passes' tiles where a plan has a choice -- single precision at N = 2048: 128 bytes = 2048 rows x 16
+ * columns exchanged through LDS as real and imaginary halves, 32 points per thread; 64 bytes = 2048 rows x 8 columns, 16 points
+ * per thread (the form of rounds 1-3, which the slab-decomposed path's k_z-chunk launches keep).  0 = the library's choice per
+ * pass class (the plain passes wide, the fused generator and binning passes narrow: they need their registers for the parked
+ * stores / the second tile).  Transforms are bit-identical in both forms (the same radix-8/8/8/4 stages); the binning pass groups
+ * its single-precision partial sums differently (1e-9 relative on a bin). */
+int fb_set_tile_rows(fb_plan* plan, int bytes);
 /* Fused log-normal transforms (pre_exp of fb_fft_r2c / fb_power_spectrum_device / _pending) form exp(x - shift).  The
  * estimate exp(d)/mean(exp(d)) - 1 does not depend on the shift (results[2 nbins] is the sum of the SHIFTED exponentials,
  * which is what the caller normalises with); the right shift keeps a single-precision plan's sum of exponentials (the

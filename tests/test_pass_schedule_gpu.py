@@ -88,3 +88,35 @@ def test_resident_schedule_in_the_slab_path(P):
         out.append((dx, sum(r.cpu().numpy() for r in res)))
     assert np.array_equal(out[0][0], out[1][0])
     assert np.allclose(out[0][1], out[1][1], rtol=1e-12, atol=0)
+
+
+def test_wide_row_form_equals_narrow_form_at_2048():
+    """N = 2048, single precision: the strided passes in 128-byte rows (2048 x 16 tile exchanged as real / imaginary halves, 32
+    points per thread -- the default) against the 64-byte-row form of rounds 1-3 (fb_set_tile_rows(64)): the same radix-8/8/8/4
+    stages, so delta_x agrees bit for bit (sum, sum of squares, maximum by fixed-order device reductions; a probe plane compared
+    element by element); both spectra -- Gaussian through the r2c route, log-normal through the fused z pass -- to 1e-7: a lane of
+    the binning pass sums its 16 or 32 modes in single precision before the fp64 wave rows, so the two forms group differently
+    (measured 1e-9).  Both schedules of the new form."""
+    from fastbox_amd import CosmoBox, default_cosmo
+    out = []
+    for rows, sched in ((64, (-1, -1, -1)), (128, (-1, -1, -1)), (128, (0, 0, 0))):
+        box = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=2048, realise_now=False, precision="f32", rng="device", seed=29)
+        box.engine.set_tile_rows(rows)
+        box.engine.set_pass_schedule(*sched)
+        dx = box.realise_density()
+        ln = box.binned_power_spectrum(delta_x=box.lognormal(dx), nbins=20)           # GEN, y, fused z, y, BIN
+        pk = box.binned_power_spectrum(delta_x=dx, nbins=20)                            # r2c, y, BIN
+        eng = box.engine
+        probe = np.stack([eng.download_plane(dx, ix) for ix in (0, 1000, 2047)])
+        out.append((eng.sum_real(dx), eng.sum_real(dx, squared=True), eng.max_real(dx), probe, pk, ln))
+        del dx
+        eng.close()
+    a = out[0]
+    for b in out[1:]:
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+        assert np.array_equal(a[3], b[3])
+        for q in (4, 5):
+            m = ~np.isnan(a[q][1])
+            assert np.array_equal(a[q][0], b[q][0]) and np.array_equal(np.isnan(a[q][1]), np.isnan(b[q][1]))
+            assert np.allclose(a[q][1][m], b[q][1][m], rtol=1e-7, atol=0), np.max(np.abs(a[q][1][m] / b[q][1][m] - 1))
+            assert np.allclose(a[q][2][m], b[q][2][m], rtol=1e-6, atol=1e-9 * a[q][1][m].max())

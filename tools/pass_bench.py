@@ -22,10 +22,14 @@ cases = (("y plain", 1, 0, nbytes), ("x plain", 0, 0, nbytes), ("x gen  ", 0, 1,
 staggers = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]      # resident form: start-up delay of the
 res = {}                                                                                 # second workgroup of a CU, x64 cycles
 variants = [(0, 0)] + [(1, st) for st in staggers]
+if N == 2048 and prec == "f32":      # the second number is then the tile's row segment in bytes (fb_set_tile_rows)
+    variants = [(0, 64), (1, 64), (0, 128), (1, 128)]
 for rnd in range(rounds + 1):
     for name, axis, mode, traffic in cases:
         for sched, stag in variants:
             eng.set_pass_schedule(sched, sched, sched)
+            if N == 2048 and prec == "f32":
+                eng.set_tile_rows(stag)
             eng.profile_start()
             for _ in range(reps):
                 _lib.call("fb_debug_strided_pass", eng._plan, h.ptr, axis, mode, eng.stream)

@@ -91,7 +91,7 @@ __device__ __forceinline__ unsigned add_word(unsigned* p, unsigned v, bool agent
                  : __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // exact read: an atomic read-modify-write is performed where the counter's adds are (memory side for agent scope, the XCD's L2 for
-// workgroup scope); a relaxed sc1 load may be served from a line the L2 fetched for an earlier poll
+// workgroup scope) -- used where a decision is taken on a NEGATIVE observation (belt and braces: no stale sc1 poll was ever observed)
 __device__ __forceinline__ unsigned rmw_read(unsigned* p, bool agent) { return add_word(p, 0u, agent); }
 constexpr int SPIN_LIMIT = 1 << 21;        // x ~0.2 us: a wait that long is a failure, never an open spin
 
@@ -118,8 +118,8 @@ __device__ __forceinline__ bool team_barrier(unsigned* team, unsigned target, un
         }
         sh[0] = ok;
         if (want_seq) {      // the team's next plane (published by the leader before it arrived; polled only by the no-barrier variant)
-            unsigned w = poll_load(team + T_WORD);
-            while ((w >> 16) != want_seq && it < SPIN_LIMIT) { __builtin_amdgcn_s_sleep(2); ++it; w = poll_load(team + T_WORD); }
+            unsigned w = poll_load(team + T_WORD + (want_seq & 1u));
+            while ((w >> 16) != want_seq && it < SPIN_LIMIT) { __builtin_amdgcn_s_sleep(2); ++it; w = poll_load(team + T_WORD + (want_seq & 1u)); }
             sh[1] = w;
         }
         if (!(flags & (F_NO_ACQUIRE | F_SC1_LOADS))) {
@@ -161,14 +161,16 @@ __global__ __launch_bounds__(NT, 8) void k_plane_team(Args a) {
     unsigned* team = ctl + W_TEAMS + team_id * 64;
     __syncthreads();
     if (in_team) {
-        // first plane: the leader draws it and publishes (sequence number in the high half)
+        // first plane: the leader draws it and publishes (sequence number in the high half).  Two alternating slots: the word of
+        // plane k + 1 is published while slow members may still be waiting for the word of plane k (the first version had ONE slot
+        // and overwrote word 1 with word 2 at once: members dispatched late never saw word 1 and their team hung at its first barrier)
         if (threadIdx.x == 0) {
             if (m == 0) {
                 const unsigned p = __hip_atomic_fetch_add(ctl + W_NEXT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(team + T_WORD, (1u << 16) | (p < 0xffffu ? p : 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(team + T_WORD + 1, (1u << 16) | (p < 0xffffu ? p : 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             int it = 0; unsigned w = 0;
-            while (it < SPIN_LIMIT) { w = poll_load(team + T_WORD); if ((w >> 16) == 1u) break; __builtin_amdgcn_s_sleep(2); ++it; }
+            while (it < SPIN_LIMIT) { w = poll_load(team + T_WORD + 1); if ((w >> 16) == 1u) break; __builtin_amdgcn_s_sleep(2); ++it; }
             if (it >= SPIN_LIMIT) __hip_atomic_store(ctl + W_ERROR, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sh[0] = it < SPIN_LIMIT; sh[1] = w;
         }
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(NT, 8) void k_plane_team(Args a) {
             char* rplane = a.real + (long long)cur * RPLANE;
             if (threadIdx.x == 0 && m == 0) {      // the leader draws the team's next plane before it arrives at the first barrier
                 const unsigned p = __hip_atomic_fetch_add(ctl + W_NEXT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(team + T_WORD, ((seq + 1) << 16) | (p < 0xffffu ? p : 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(team + T_WORD + ((seq + 1) & 1u), ((seq + 1) << 16) | (p < 0xffffu ? p : 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             phase_y<0>(plane, m, a.delay);             // (first touch of the plane by this launch: plain loads)
             ok = team_barrier(team, ++bar * TEAM, ctl, a.flags, sh, (seq + 1) & 0xffffu);

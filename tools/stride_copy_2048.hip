@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
+template <int U>
 __global__ __launch_bounds__(1024) void k_tile(const char* __restrict__ in, char* __restrict__ out, long long stride,
                                                long long outer_stride, long long tile_stride, int seg, int rows, int ntx, int ntiles, int mode) {
     const int lanes_per_row = seg / 8;
@@ -12,14 +13,14 @@ __global__ __launch_bounds__(1024) void k_tile(const char* __restrict__ in, char
     const int rstep = blockDim.x / lanes_per_row;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long base = (long long)(tile / ntx) * outer_stride + (long long)(tile % ntx) * tile_stride + c * 8;
-        for (int r = r0; r < rows; r += rstep * 16) {
-            double v[16];
+        for (int r = r0; r < rows; r += rstep * U) {
+            double v[U];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = (mode != 2 && r + u * rstep < rows) ? *(const double*)(in + base + (long long)(r + u * rstep) * stride) : 1.0;
-            if (mode == 1) { double acc = 0; for (int u = 0; u < 16; ++u) acc += v[u]; if (acc == 1.2345) out[0] = 1; }
+            for (int u = 0; u < U; ++u) v[u] = (mode != 2 && r + u * rstep < rows) ? *(const double*)(in + base + (long long)(r + u * rstep) * stride) : 1.0;
+            if (mode == 1) { double acc = 0; for (int u = 0; u < U; ++u) acc += v[u]; if (acc == 1.2345) out[0] = 1; }
             else {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) if (r + u * rstep < rows) *(double*)(out + base + (long long)(r + u * rstep) * stride) = v[u];
+                for (int u = 0; u < U; ++u) if (r + u * rstep < rows) *(double*)(out + base + (long long)(r + u * rstep) * stride) = v[u];
             }
         }
     }
@@ -32,7 +33,7 @@ int main() {
     if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMemset(a, 1, bytes); hipMemset(b, 0, bytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    struct Cfg { const char* name; long long stride, outer, tile; int nouter, ntx; };
+    struct Cfg { const char* name; long long stride, outer, tile; int nouter, ntx; long long seg = 64; int U = 16; };
     const long long row = NZP * 8, plane = NR * row;
     Cfg cfgs[] = {
         {"now  y pass (rows 8320 B apart, tiles of a plane adjacent)", row, plane, seg, 256, 130},
@@ -43,16 +44,23 @@ int main() {
         {"TM   x pass (rows 128 KB + 256 B apart)                  ", (N + 4) * seg, seg, N * (N + 4) * seg, 256, 130},
         {"TM   x pass (rows 128 KB + 2112 B apart)                 ", (N + 33) * seg, seg, N * (N + 33) * seg, 256, 130},
         {"TM   y pass with the 33-row pad                           ", seg, (N + 33) * seg, N * (N + 33) * seg, 256, 130},
+        // round 4 (VERDICT r3 Next 3): the same layout read in 128-byte row segments -- 2048 rows x 16 columns, 32 points per thread
+        // (16 or all 32 loads of a thread in flight)
+        {"128B y pass (rows 8320 B apart), 16 in flight             ", row, plane, 128, 256, 65, 128, 16},
+        {"128B y pass (rows 8320 B apart), 32 in flight             ", row, plane, 128, 256, 65, 128, 32},
+        {"128B x pass (rows 17.0 MB apart), 16 in flight            ", plane, row, 128, 256, 65, 128, 16},
+        {"128B x pass (rows 17.0 MB apart), 32 in flight            ", plane, row, 128, 256, 65, 128, 32},
     };
     for (auto& cf : cfgs)
         for (int mode : {0, 1, 2}) {
             const int ntiles = cf.ntx * cf.nouter;                      // 256 of the 2048 outer indices: 1/8 of a pass
-            const double moved = 2.0 * (double)ntiles * seg * N;
+            const double moved = 2.0 * (double)ntiles * cf.seg * N;
             for (int blocks : {256, 512}) {
                 float best = 1e9f;
                 for (int rep = 0; rep < 4; ++rep) {
                     hipEventRecord(e0);
-                    hipLaunchKernelGGL(k_tile, dim3(blocks), dim3(1024), 0, 0, a, b, cf.stride, cf.outer, cf.tile, (int)seg, (int)N, cf.ntx, ntiles, mode);
+                    if (cf.U == 32) hipLaunchKernelGGL(k_tile<32>, dim3(blocks), dim3(1024), 0, 0, a, b, cf.stride, cf.outer, cf.tile, (int)cf.seg, (int)N, cf.ntx, ntiles, mode);
+                    else hipLaunchKernelGGL(k_tile<16>, dim3(blocks), dim3(1024), 0, 0, a, b, cf.stride, cf.outer, cf.tile, (int)cf.seg, (int)N, cf.ntx, ntiles, mode);
                     hipEventRecord(e1); hipEventSynchronize(e1);
                     float ms; hipEventElapsedTime(&ms, e0, e1);
                     if (ms < best) best = ms;
