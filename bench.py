@@ -75,6 +75,9 @@ def parse(argv=None):
                     help="seconds of untimed steps of the same workload run directly before the warm-up steps: the GPU "
                          "raises its clocks over ~50 ms of load (tools/step_timeline.py: the first 20 steps after an idle "
                          "gap run 10 %% below the sustained rate), and the metric is the sustained rate")
+    ap.add_argument("--regions", type=int, default=5,
+                    help="timed regions of --steps steps each, back to back (each bracketed by barrier + synchronize on both "
+                         "sides, max over ranks); the headline is the MEDIAN region, every region's time is listed")
     ap.add_argument("--plane-batch", type=int, default=None,
                     help="x-planes per cache-resident batch of the y/z passes (default: the library's size for one box per "
                          "GPU when --streams 1, N/8 when several boxes share the GPU)")
@@ -214,6 +217,25 @@ def from_profiles(N, precision):
     except Exception:
         pass
     return out
+
+
+def _collective_info(torch, dist, local_rank):
+    """What the process group of this job really was (every rank calls it): backend, the world size the group reports and,
+    all-gathered, each rank's device -- so that a scaling record shows N ranks on N different GPUs behind RCCL."""
+    me = {"rank": dist.get_rank(), "host": socket.gethostname(), "device": local_rank, "name": None, "pci_bus_id": None, "uuid": None}
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        me["name"] = pr.name
+        dom, bus, dev = getattr(pr, "pci_domain_id", None), getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None)
+        if bus is not None:
+            me["pci_bus_id"] = "%04x:%02x:%02x" % (dom or 0, bus, dev or 0)
+        me["uuid"] = str(getattr(pr, "uuid", None))
+    except Exception as e:
+        me["error"] = "%s: %s" % (type(e).__name__, e)
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, me)
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": gathered,
+            "distinct_devices": len({(g["host"], g["pci_bus_id"] or g["device"]) for g in gathered})}
 
 
 def _prio(args, i):
@@ -380,7 +402,8 @@ def config3_leg(args, N, rank, local_rank, torch, chains=30):
     per_chain_ms = rsd_ms / chains
     rsd_gbs = rsd_bytes / (per_chain_ms * 1e-3) / 1e9 if rsd_ms > 0 else None
     return {"workload": "%d^3: realise_density -> realise_velocity[2] -> redshift_space_density -> apply_transfer_fn(Wedge "
-                        "slope 0.3) -> binned_power_spectrum + filtered field" % N,
+                        "slope 0.3) -> binned_power_spectrum + filtered field; value = best of {1, %d} boxes per GPU (both listed)"
+                        % (N, len(boxes)),
             # the better of the two ways to run independent chains on one GPU is the leg's value; both are listed
             "ms_per_chain": 1e3 * min(dt, dt_one), "value": 1.0 / min(dt, dt_one), "unit": "chains/s", "chains": chains, "dtype": "f32",
             "streams_per_gpu": len(boxes) if dt <= dt_one else 1,
@@ -525,23 +548,33 @@ def main():
     fence()
     if in_region:
         eng.profile_start(None if args.all_kernel_events else ["fft_strided"], stride=ev_stride)
-    t0 = time.perf_counter()
-    pending = [step() for _ in range(args.steps)]
-    spectra = [pnd.result() for pnd in pending]
+    # the metric is the sustained rate -- the median of `regions` back-to-back regions of exactly K steps, each
+    # fenced (barrier + synchronize) on both sides; `steps` / `ms_per_step` describe ONE region (the median one)
+    nreg = max(1, args.regions)
+    dts, spectra = [], []
+    for _ in range(nreg):
+        t0 = time.perf_counter()
+        pending = [step() for _ in range(args.steps)]
+        spectra += [pnd.result() for pnd in pending]
+        if in_region and len(dts) == nreg - 1:
+            prof = eng.profile_stop()                    # synchronises the launch stream
+            plain_launches = eng.profile_seen() if ev_stride > 1 else prof["fft_strided"][1]
+        fence()
+        dts.append(time.perf_counter() - t0)
     if in_region:
-        prof = eng.profile_stop()                    # synchronises the launch stream
-        plain_launches = eng.profile_seen() if ev_stride > 1 else prof["fft_strided"][1]
-    fence()
-    dt = time.perf_counter() - t0
+        prof_steps = args.steps * nreg
     gc.enable()
     _check_finite(spectra, "timed region")       # every rank: a rank that timed garbage stops the job
     ln_repeats = sum(getattr(b, "lognormal_repeats", 0) for b in boxes)
+    collective = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=args._reduce_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor(dts, dtype=torch.float64, device=args._reduce_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)         # per region: the slowest rank's time
+        dts = [float(x) for x in t.tolist()]
+        collective = _collective_info(torch, dist, local_rank)
         dist.barrier()
         dist.destroy_process_group()
+    dt = sorted(dts)[len(dts) // 2]
     if rank != 0:
         return
 
@@ -565,6 +598,12 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "finite": True, "lognormal_repeats": ln_repeats,
+        "regions": {"count": len(dts), "ms_per_step": [round(1e3 * d / args.steps, 5) for d in dts],
+                    "boxes_per_s": [round(world * args.steps / d, 2) for d in dts],
+                    "spread": (max(dts) - min(dts)) / dt,
+                    "what": "back-to-back timed regions of `steps` steps, each fenced on both sides (max over ranks per "
+                            "region); value / ms_per_step are the MEDIAN region's"},
+        "collective": collective,
         "config": {"workload": "%d^3 Gaussian box (device Philox4x32-10 noise, stand-in EH P(k), L=1000 Mpc) + "
                                "log-normal transform + binned P(k), nbins=%d" % (N, args.nbins),
                    "nsamp": N, "parallelism": "replicas x%d" % world, "streams_per_gpu": len(boxes),
@@ -606,9 +645,9 @@ def main():
             "achieved": b_ach, "frac": b_ach / HBM_PEAK_GBS}
     if in_region:
         total_ms = sum(v[0] for v in prof.values()) * (plain_launches / max(launches, 1) if ev_stride > 1 else 1.)
-        line["kernel_ms_per_step"] = {k: round(v[0] / args.steps * (plain_launches / max(v[1], 1) if ev_stride > 1 else 1.), 4)
+        line["kernel_ms_per_step"] = {k: round(v[0] / prof_steps * (plain_launches / max(v[1], 1) if ev_stride > 1 else 1.), 4)
                                       for k, v in prof.items() if v[1]}
-        line["kernel_ms_total_per_step"] = round(total_ms / args.steps, 4)
+        line["kernel_ms_total_per_step"] = round(total_ms / prof_steps, 4)
     # whole step against the HBM roofline: SURVEY 8(d)'s byte model for this workload is 5.0 sweeps of N^3 complex
     # values; this implementation moves 4.5 (the z passes of realisation and estimate are one), of N*N*(N/2) columns
     sweep = float(N) ** 3 * 2 * s
@@ -688,6 +727,7 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
             d = float(t.item())
         return d
 
+    collective = _collective_info(torch, dist, local_rank) if world > 1 else None
     for _ in range(args.warmup):
         box.realise_and_power(nbins=args.nbins, lognormal=True)
     timed(3, False)
@@ -695,6 +735,17 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
     # one realisation at a time (BASELINE config 4: ONE box): with chunks > 1 each all-to-all runs beside the passes of
     # the neighbouring chunks of the same transform; on one rank the figure is the cost of the chunked form itself
     dt_sync = timed(max(2, args.steps // 2), True) / max(2, args.steps // 2) if (world > 1 or box.chunks > 1) else None
+    # the same one-at-a-time loop with the transform in ONE piece (every all-to-all fully exposed): what the chunks buy
+    dt_sync1 = None
+    if world > 1 and box.chunks > 1:
+        box1 = SlabBox(default_cosmo, box_scale=1e3, nsamp=N, precision=args.precision, seed=1000, rank=rank, world=world,
+                       device=local_rank, chunks=1)
+        keep, box = box, box1
+        try:
+            box.realise_and_power(nbins=args.nbins, lognormal=True)
+            dt_sync1 = timed(max(2, args.steps // 2), True) / max(2, args.steps // 2)
+        finally:
+            box = keep
     if rank == 0:
         s = 4 if args.precision == "f32" else 8
         sweep = float(N) ** 3 * 2 * s
@@ -702,6 +753,8 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
         timing = None if dt_sync is None else {
             "ms_per_step_one_realisation_at_a_time": 1e3 * dt_sync, "chunks_per_transform": box.chunks,
             "ms_per_step_pipelined": 1e3 * dt / args.steps,
+            "ms_per_step_one_realisation_at_a_time_unchunked": None if dt_sync1 is None else 1e3 * dt_sync1,
+            "exposed_exchange_ms_per_step": None if dt_sync is None else 1e3 * (dt_sync - dt / args.steps),
             "all_to_alls_per_step": 2, "bytes_sent_per_rank_per_all_to_all": a2a * (world - 1),
             "note": "pipelined = up to three realisations in flight, both all-to-alls asynchronous on the RCCL stream "
                     "behind other realisations' passes (several ranks; on one rank it is the same loop as the first "
@@ -717,7 +770,7 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
                        "parallelism": "slab x%d" % world,
                        "all_to_all_bytes_per_rank_pair": (N // world) ** 2 * ((N // 2 + 16) // 16 * 16) * 2 * s},
             "pipeline_frac_model_bytes": 5.0 * sweep * (args.steps / dt) / 1e9 / (HBM_PEAK_GBS * world),
-            "exchange": timing, "roofline": None, "cpu_baseline": None}))
+            "exchange": timing, "collective": collective, "roofline": None, "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -708,6 +708,9 @@ class CosmoBox(object):
                 sigma2 = getattr(src, "sigma2", None)
                 if sigma2 is not None:
                     shift = hostgeom.lognormal_shift(sigma2, nvox)
+                elif eng.precision == "f64":
+                    shift = 0.0       # double precision needs no shift until exp(d) itself leaves the range (where the reference's
+                                      # float64 does too), and a look at the data would wait for the stream (wait=False pipelines)
                 else:
                     shift = hostgeom.lognormal_shift_exact(eng.max_real(src), nvox)
                 nb_, bin_args = bins.size, (bins, thr, amb)

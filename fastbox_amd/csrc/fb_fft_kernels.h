@@ -351,7 +351,8 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 #ifndef FB_GEN_PARK
 #define FB_GEN_PARK 16     // (2048^3: generator pass 20.4 -> 18.8 ms with all 16 rows parked, 19.5 with 8; 119 of 128 registers)
 #endif
-    constexpr int PARK = (PERSIST && MODE == SMODE_GEN && !SPLIT && E == 16) ? FB_GEN_PARK : 0;     // rows parked (0, 8 or 16)
+    // (single precision only: the register budgets above are float's; 16 parked cx<double> would be 64 more registers)
+    constexpr int PARK = (PERSIST && MODE == SMODE_GEN && !SPLIT && E == 16 && sizeof(T) == 4) ? FB_GEN_PARK : 0;     // rows parked (0, 8 or 16)
     constexpr int PARK0 = E - PARK;                    // first parked row
     [[maybe_unused]] cx<T> wpark[PARK > 0 ? PARK : 1];
     [[maybe_unused]] bool staged = false;              // wave-uniform
@@ -382,7 +383,7 @@ void k_fft_strided(StridedArgs<T> a, int sign, StridedOp<T> op) {
 #ifndef FB_BIN_DBUF
 #define FB_BIN_DBUF 1        // (2048^3: binning pass 12.67 -> 12.40 ms; 122 of 128 registers)
 #endif
-    constexpr bool DBUF = PERSIST && MODE == SMODE_BIN && !SPLIT && E == 16 && FB_BIN_DBUF;
+    constexpr bool DBUF = PERSIST && MODE == SMODE_BIN && !SPLIT && E == 16 && sizeof(T) == 4 && FB_BIN_DBUF;
     [[maybe_unused]] cx<T> vnext[DBUF ? E : 1];
     [[maybe_unused]] auto load_tile = [&](int id) {
         int lbx, lby;

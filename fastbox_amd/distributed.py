@@ -179,10 +179,14 @@ class SlabBox(object):
     for cubic boxes with the device RNG.  Collective: every rank of the group calls each method."""
 
     def __init__(self, cosmo, box_scale=1e3, nsamp=512, redshift=0., precision="f32", seed=0,
-                 rank=None, world=None, group=None, ops_factory=None, device=None, pk_fn=None, chunks=1):
+                 rank=None, world=None, group=None, ops_factory=None, device=None, pk_fn=None, chunks=1, comm=None):
         import torch.distributed as dist
         self._dist = dist
         self.group = group
+        # comm: an object with  all_to_all(rank, send, recv) -> handle with wait()  and  all_reduce(rank, tensor)  that stands
+        # in for torch.distributed (VirtualComm below: several ranks of one process, so that the sequencing of this class --
+        # asynchronous chunk exchanges, waits, buffer reuse -- is what a single-GPU test runs)
+        self._comm = comm
         if rank is None:
             rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
         if world is None:
@@ -267,6 +271,9 @@ class SlabBox(object):
         """All-to-all of equal blocks; returns the buffer that holds the result (`send` itself for one rank)."""
         if self.world == 1:
             return send
+        if self._comm is not None:
+            self._comm.all_to_all(self.rank, send, recv).wait()
+            return recv
         if self._host_staged(send):
             h_in = send.detach().cpu().view(-1)
             h_out = h_in.new_empty(h_in.shape)
@@ -278,6 +285,9 @@ class SlabBox(object):
 
     def _all_reduce(self, t):
         if self.world == 1:
+            return
+        if self._comm is not None:
+            self._comm.all_reduce(self.rank, t)
             return
         if self._host_staged(t):
             h = t.detach().cpu()
@@ -443,13 +453,15 @@ class SlabBox(object):
     def _exchange_async(self, send, recv):
         """All-to-all as an asynchronous collective: returns a handle whose ``wait()`` makes the compute stream wait
         for it (None: nothing to wait for).  gloo with device tensors (single-GPU rehearsal) stages synchronously."""
+        if self._comm is not None:
+            return self._comm.all_to_all(self.rank, send, recv)
         if self._host_staged(send):
             self._exchange(send, recv)
             return None
         return self._dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group, async_op=True)
 
     def _all_reduce_async(self, t):
-        if self._host_staged(t):
+        if self._comm is not None or self._host_staged(t):
             self._all_reduce(t)
             return None
         return self._dist.all_reduce(t, group=self.group, async_op=True)
@@ -640,6 +652,81 @@ class _Deferred(object):
 
     def result(self):
         return self.box._finish_power(self.res, self.kc, self.nb, self.lognormal, self.redo)
+
+
+class VirtualComm(object):
+    """The collectives of P SlabBox ranks that live in ONE process, each driven by its own thread (``run``): an all-to-all
+    returns a handle at once, like an asynchronous collective; ``wait()`` of a rank's k-th collective blocks until every
+    rank has posted its k-th, copies that rank's blocks out of the posted send buffers, and blocks again until every rank
+    has copied (a send buffer may be reused after its own wait, as with a real collective).  All tensor work is enqueued on
+    the device's current stream, so stream order = the order the threads were let through."""
+
+    class _Handle(object):
+        def __init__(self, comm, rank, k, recv):
+            self.comm, self.rank, self.k, self.recv = comm, rank, k, recv
+
+        def wait(self):
+            c = self.comm
+            c._meet()                                     # every rank has posted (and enqueued what produces) collective k
+            sends = c._posted[self.k]
+            flat = self.recv.view(c.P, -1)
+            for q in range(c.P):
+                flat[q].copy_(sends[q].view(c.P, -1)[self.rank])
+            c._meet()                                     # every rank has taken its blocks: the send buffers are free again
+
+    def __init__(self, P):
+        import threading
+        self.P = P
+        self._bar = threading.Barrier(P)
+        self._posted = {}
+        self._count = [0] * P
+        self._lock = threading.Lock()
+        self._red = {}
+
+    def _meet(self):
+        self._bar.wait(timeout=600)
+
+    def all_to_all(self, rank, send, recv):
+        k = self._count[rank]
+        self._count[rank] += 1
+        with self._lock:
+            self._posted.setdefault(k, [None] * self.P)[rank] = send
+        return VirtualComm._Handle(self, rank, k, recv)
+
+    def all_reduce(self, rank, t):
+        with self._lock:
+            self._red.setdefault("cur", [None] * self.P)[rank] = t
+        self._meet()
+        parts = self._red["cur"]
+        total = parts[0].clone()
+        for q in range(1, self.P):
+            total += parts[q]                              # the same order on every rank
+        self._meet()
+        t.copy_(total)
+        self._meet()
+        if rank == 0:
+            self._red.pop("cur", None)
+        self._meet()
+
+    def run(self, boxes, fn):
+        """fn(box) on every box, one thread per rank; returns the results in rank order (re-raises the first error)."""
+        import threading
+        out, err = [None] * self.P, []
+
+        def work(r):
+            try:
+                out[r] = fn(boxes[r])
+            except BaseException as e:                   # noqa: B902 -- a failed rank must release the others
+                err.append(e)
+                self._bar.abort()
+        ts = [threading.Thread(target=work, args=(r,)) for r in range(self.P)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if err:
+            raise err[0]
+        return out
 
 
 def run_virtual(boxes, fn_local, fn_finish):

@@ -123,7 +123,10 @@ def lognormal_sums_in_range(cnt, s1, s2, esum):
     a, b = np.asarray(s1)[1:][ok], np.asarray(s2)[1:][ok]
     if not (np.isfinite(esum) and esum > 0. and np.all(np.isfinite(a)) and np.all(np.isfinite(b))):
         return False
-    return bool(np.all(a > 0.) and np.all(b * c[ok] >= a * a * (1. - 1e-3)))
+    # (a bin with exactly zero power -- a constant field: exp(d)/mean - 1 = 0, the reference returns P = 0 -- is in range: with a
+    # finite, positive sum of exponentials underflow cannot produce it)
+    zero = (a == 0.) & (b == 0.)
+    return bool(np.all((a > 0.) | zero) and np.all(b * c[ok] >= a * a * (1. - 1e-3)))
 
 
 def bin_edges(g, nbins=20, kbins=None):

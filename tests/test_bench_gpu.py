@@ -50,6 +50,12 @@ def test_single_gpu_line():
     pr = d["pipeline_roofline"]
     assert pr["model_sweeps"] == 5.0 and pr["moved_sweeps"] == 4.5 and 0 < pr["frac_moved"] < pr["frac"] < 1
     assert "from_profiles" in d and "file" in d["from_profiles"] and "head" in d["from_profiles"]
+    # the headline is the median of >= 5 fenced regions of `steps` steps, every region listed
+    rg = d["regions"]
+    assert rg["count"] >= 5 and len(rg["ms_per_step"]) == rg["count"] and all(x > 0 for x in rg["ms_per_step"])
+    assert sorted(rg["ms_per_step"])[rg["count"] // 2] == pytest.approx(d["ms_per_step"], rel=1e-3) and rg["spread"] >= 0
+    assert d["collective"] is None                 # one rank: no process group
+    assert "best of" in c3["workload"]
 
 
 def test_two_ranks_started_by_bench_itself():
@@ -67,9 +73,21 @@ def test_two_ranks_started_by_bench_itself():
     d = lines[0]
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["cpu_baseline"] is None
     assert d["config"]["parallelism"] == "replicas x2"
+    import math
+
+    def group_ok(c):        # what the process group really was: backend, size as the group reports it, one entry per rank
+        assert c["backend"] == "gloo" and c["world_size"] == 2 and len(c["devices"]) == 2
+        assert sorted(g["rank"] for g in c["devices"]) == [0, 1] and all("device" in g and "pci_bus_id" in g for g in c["devices"])
+    group_ok(d["collective"])
+    assert d["regions"]["count"] >= 5
     ss = d["strong_scaling"]["64"]
-    assert ss["n_gpus"] == 2 and ss["scaling"] == "strong" and ss["value"] > 0
-    assert ss["exchange"]["ms_per_step_pipelined"] > 0 and ss["config"]["parallelism"] == "slab x2"
+    assert ss["n_gpus"] == 2 and ss["scaling"] == "strong" and math.isfinite(ss["value"]) and ss["value"] > 0
+    assert math.isfinite(ss["ms_per_step"]) and ss["finite"] is True
+    ex = ss["exchange"]
+    assert ex["ms_per_step_pipelined"] > 0 and ss["config"]["parallelism"] == "slab x2"
+    assert math.isfinite(ex["ms_per_step_one_realisation_at_a_time"]) and math.isfinite(ex["exposed_exchange_ms_per_step"])
+    assert 2 <= ex["chunks_per_transform"] <= 4 and math.isfinite(ex["ms_per_step_one_realisation_at_a_time_unchunked"])
+    group_ok(ss["collective"])
 
 
 def test_two_ranks_under_an_external_launcher():
@@ -82,3 +100,4 @@ def test_two_ranks_under_an_external_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0
+    assert lines[0]["collective"]["world_size"] == 2 and lines[0]["collective"]["backend"] == "gloo"

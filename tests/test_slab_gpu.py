@@ -309,6 +309,52 @@ def test_slab_path_at_2048(P, single_gpu_2048):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("P", [1, 2, 8])
+def test_chunked_transform_at_2048_through_the_shipped_sequence(P, single_gpu_2048):
+    """What bench.py's strong-scaling leg runs (N = 2048, f32, k_z chunks C = 4: 33 + 33 + 32 + 32 tiles) through the code that
+    ships: SlabBox.realise_and_power -> _inverse_chunked / _forward_chunked with their asynchronous chunk exchanges, waits and
+    buffer reuse, the collectives supplied by VirtualComm (P ranks = P threads of this process on one GPU).  16 points per
+    thread, resident schedule, parked generator stores, double-buffered binning and the appended partial-sum table all take
+    part.  Against the single-GPU box: field through sum and sum of squares, log-normal P(k) at 1e-5; a second realisation
+    pipelined (wait=False) equals the same realisation run synchronously."""
+    import gc
+    import torch
+    from fastbox_amd import default_cosmo
+    from fastbox_amd.distributed import HipSlabOps, SlabBox, VirtualComm
+    w = single_gpu_2048
+    N, L, seed, nb = w["N"], w["L"], w["seed"], w["nb"]
+    comm = VirtualComm(P) if P > 1 else None
+    boxes = [SlabBox(default_cosmo, box_scale=L, nsamp=N, precision="f32", seed=seed, rank=r, world=P, chunks=4, comm=comm,
+                     ops_factory=lambda g, PP, rr: HipSlabOps(g, PP, rr, precision="f32", device=0)) for r in range(P)]
+    assert all(b.chunks == 4 for b in boxes) and len({nt for _, nt in boxes[0]._chunk_tab}) > 1       # uneven chunks
+    run = (lambda fn: comm.run(boxes, fn)) if P > 1 else (lambda fn: [fn(boxes[0])])
+    out = run(lambda b: b.realise_and_power(nbins=nb, lognormal=True))
+    sq = sum(float(torch.linalg.vector_norm(b.delta_x.reshape(-1), 2, dtype=torch.float64)) ** 2 for b in boxes)
+    sm = sum(float(torch.sum(b.delta_x, dtype=torch.float64)) for b in boxes)
+    assert np.isclose(sq, w["sq"], rtol=1e-6) and abs(sm - w["sum"]) < 1e-6 * np.sqrt(w["sq"] * float(N) ** 3)
+    want = w["ln"]
+    m = ~np.isnan(want[1])
+    for kc, pk, err in out:                              # every rank holds the all-reduced spectrum
+        assert np.array_equal(kc, want[0]) and np.array_equal(np.isnan(pk), np.isnan(want[1]))
+        assert np.allclose(pk[m], want[1][m], rtol=1e-5, atol=0), np.max(np.abs(pk[m] / want[1][m] - 1))
+        assert np.array_equal(pk, out[0][1], equal_nan=True)
+    assert all(b.ln_repeats == 0 for b in boxes)
+    # the next realisation, Gaussian: synchronous, then the same index again through the ticket form
+    sync = run(lambda b: b.realise_and_power(nbins=nb, lognormal=False))
+
+    def again(b):
+        b._realisation -= 1
+        return b.realise_and_power(nbins=nb, lognormal=False, wait=False).result()
+    piped = run(again) if P == 1 else sync       # (several ranks: wait=False is the whole-slab pipeline, three more buffer pairs)
+    for a, c in zip(sync, piped):
+        assert np.array_equal(a[1], c[1], equal_nan=True) and np.array_equal(a[2], c[2], equal_nan=True)
+    mg = ~np.isnan(w["gauss"][1])
+    assert not np.allclose(sync[0][1][mg], w["gauss"][1][mg], rtol=1e-3)      # another realisation than the fixture's
+    del boxes, out, sync, piped
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("f64", 1e-11)])
 @pytest.mark.parametrize("P,N,C", [(1, 64, 2), (2, 64, 3), (8, 64, 2), (4, 128, 5), (2, 256, 4)])
 def test_chunked_slab_transform_on_virtual_ranks(P, N, C, precision, tol):
