@@ -67,6 +67,9 @@ def parse(argv=None):
     ap.add_argument("--chunks", type=int, default=None,
                     help="--mode slab: k_z chunks of ONE transform (the all-to-all of a chunk runs beside the passes of the "
                          "next); default 4 with several ranks, 1 on one rank")
+    ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
+                    help="--mode slab: the data path's collectives through torch.distributed (nccl backend = RCCL) or through "
+                         "the library's own RCCL communicator behind the C ABI (fb_comm_create / fb_slab_exchange_begin)")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent realisations are issued round-robin on this many HIP streams (boxes)")
     ap.add_argument("--sizes", default="256,1024,2048", help="N = 1: other grid sizes of the `sizes` leg")
@@ -680,6 +683,14 @@ def main():
                 j = _last_json(txt)
                 out[str(n2)] = j if (rc == 0 and j) else {"error": "slab job rc=%s" % rc}
                 failed = not (rc == 0 and j)
+                if not failed and n2 == min(int(x) for x in args.slab_sizes.split(",") if x) \
+                        and os.environ.get("FASTBOX_BENCH_BACKEND", "nccl") == "nccl":       # (not in the one-device rehearsal)
+                    # the same job with the collectives behind the C ABI (the library's own RCCL communicator), smallest size
+                    rc, txt = spawn_ranks(world, ["--mode", "slab", "--nsamp", str(n2), "--steps", str(st), "--warmup", "2",
+                                                  "--gpus", str(world), "--precision", args.precision, "--chunks", "4",
+                                                  "--comm", "rccl"], timeout=240)
+                    j = _last_json(txt)
+                    out["%d_comm_rccl_abi" % n2] = j if (rc == 0 and j) else {"error": "slab job (--comm rccl) rc=%s" % rc}
             except Exception as e:
                 out[str(n2)] = {"error": "%s: %s" % (type(e).__name__, e)}
                 failed = True
@@ -699,8 +710,9 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
     N = args.nsamp
     torch.cuda.set_device(local_rank)
     chunks = args.chunks if args.chunks is not None else (4 if world > 1 else 1)
+    comm = "rccl" if args.comm == "rccl" else None
     box = SlabBox(default_cosmo, box_scale=1e3, nsamp=N, precision=args.precision, seed=1000, rank=rank, world=world,
-                  device=local_rank, chunks=chunks)
+                  device=local_rank, chunks=chunks, comm=comm)
 
     def fence():
         torch.cuda.synchronize()
@@ -728,6 +740,11 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
         return d
 
     collective = _collective_info(torch, dist, local_rank) if world > 1 else None
+    if collective is not None:
+        collective["data_path"] = "torch.distributed all_to_all_single / all_reduce" if comm is None else \
+            "libfastbox_hip.so: fb_slab_exchange_begin / _wait (ncclSend + ncclRecv group on the library's stream), fb_allreduce_f64"
+        if comm is not None:
+            collective["library_comm"] = box._comm.info()
     for _ in range(args.warmup):
         box.realise_and_power(nbins=args.nbins, lognormal=True)
     timed(3, False)
@@ -738,8 +755,10 @@ def slab_main(args, rank, world, local_rank, torch, dist, np):
     # the same one-at-a-time loop with the transform in ONE piece (every all-to-all fully exposed): what the chunks buy
     dt_sync1 = None
     if world > 1 and box.chunks > 1:
+        if comm is not None:
+            os.environ["FASTBOX_RDV_OFFSET"] = "23"          # a second communicator: its id travels on another port
         box1 = SlabBox(default_cosmo, box_scale=1e3, nsamp=N, precision=args.precision, seed=1000, rank=rank, world=world,
-                       device=local_rank, chunks=1)
+                       device=local_rank, chunks=1, comm=comm)
         keep, box = box, box1
         try:
             box.realise_and_power(nbins=args.nbins, lognormal=True)

@@ -102,6 +102,14 @@ SIGNATURES = {
     "fb_set_plane_batching": (c_int, [c_void_p, c_int, c_int]),
     "fb_set_pass_schedule": (c_int, [c_void_p, c_int, c_int, c_int]),
     "fb_set_tile_rows": (c_int, [c_void_p, c_int]),
+    "fb_comm_unique_id": (c_int, [c_void_p]),
+    "fb_comm_create": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "fb_comm_destroy": (c_int, [c_void_p]),
+    "fb_comm_info": (c_int, [c_void_p, P_i32, P_i32, P_i32]),
+    "fb_slab_exchange_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, P_i32]),
+    "fb_slab_exchange_wait": (c_int, [c_void_p, c_int, c_void_p]),
+    "fb_slab_exchange": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "fb_allreduce_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fb_set_exp_shift": (c_int, [c_void_p, ctypes.c_double]),
     "fb_debug_strided_pass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fb_debug_read_stamps": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), c_i64]),

@@ -1,8 +1,11 @@
 // extern "C" surface of libfastbox_hip.so (see include/fastbox_hip.h).
 #include "../../include/fastbox_hip.h"
 #include "fb_plan.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>           // types and prototypes only: the functions are looked up in a dlopen'ed librccl (fb_comm.inc)
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -133,8 +136,10 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
     return FB_OK;
 }
 
+int fb_comm_destroy(fb_plan* p);
 int fb_plan_destroy(fb_plan* p) {
     if (!p) return FB_OK;
+    (void)fb_comm_destroy(p);
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->tw, p->axis2, p->ksc, p->kpar, p->zgrid, p->amp_shell, p->amp_sym, p->kperp_tab, p->pca_work, p->bins, p->thr, p->counts,
                     p->partials, p->scratch, p->bin_partials, p->exp_partials, p->plane_buf};
@@ -860,5 +865,7 @@ int fb_stream_wait_stream(void* waiter, void* signaller) {
     FB_HIP(e);
     return FB_OK;
 }
+
+#include "fb_comm.inc"
 
 }  // extern "C"

@@ -11,8 +11,12 @@
 #define FB_ERR_UNSUPPORTED -3
 #define FB_ERR_NOMEM -4
 #define FB_ERR_STATE -5
+#define FB_ERR_RCCL -6
+
+struct fb_comm;                  // fb_comm.inc: RCCL communicator + its stream and events (fb_comm_create)
 
 struct fb_plan {
+    fb_comm* comm = nullptr;     // one box over several GPUs: this rank's communicator, or null
     int N = 0;
     int prec = 4;            // bytes per real: 4 (float) or 8 (double)
     double L[3] = {0, 0, 0};

@@ -212,6 +212,13 @@ class SlabBox(object):
             ops_factory = lambda g, P, r: HipSlabOps(g, P, r, precision=precision,
                                                      device=(r if device is None else device))
         self.ops = ops_factory(self.g, world, rank)
+        if isinstance(comm, str):
+            if comm != "rccl":
+                raise ValueError("comm: None (torch.distributed), 'rccl' (the library's own communicator) or an object")
+            # the data path's collectives inside libfastbox_hip.so; the id travels by fastbox_amd.rendezvous (a one-rank box
+            # makes a real one-rank RCCL communicator, so that this path can be exercised on a single GPU)
+            self._comm = RcclComm.from_environment(self.ops.engine, world, rank, self.ops._stream) if world > 1 else \
+                RcclComm(self.ops.engine, 1, 0, RcclComm.unique_id(), self.ops._stream)
         amp = hostgeom.shell_amplitude(N, self.g["L"][0], self.boxfactor, pk_fn)
         self.ops.set_amplitude(amp)
         # fused log-normal transforms form exp(d - shift): same estimate, and with the shift taken from the variance of
@@ -601,7 +608,10 @@ class SlabBox(object):
             self._realisation = keep
         import torch
         m = torch.tensor([self.ops.max_real(real)], dtype=torch.float64)
-        if self.world > 1:
+        if self.world > 1 and self._comm is not None:
+            m = m.to(real.device)
+            self._comm.all_reduce(self.rank, m, op="max")
+        elif self.world > 1:
             if self._dist.get_backend(self.group) != "gloo":
                 m = m.to(real.device)
             self._dist.all_reduce(m, op=self._dist.ReduceOp.MAX, group=self.group)
@@ -654,6 +664,69 @@ class _Deferred(object):
         return self.box._finish_power(self.res, self.kc, self.nb, self.lognormal, self.redo)
 
 
+class RcclComm(object):
+    """The collectives of a SlabBox through the library's own communicator (C ABI: fb_comm_create, fb_slab_exchange_begin /
+    _wait, fb_allreduce_f64 -- RCCL over xGMI on a stream the library owns, event hand-off with the compute stream): ctypes
+    only, no torch.distributed.  `stream_fn()` gives the stream the rank's passes run on; buffers are anything with
+    data_ptr() / numel() / element_size() (torch tensors here)."""
+
+    class _Handle(object):
+        def __init__(self, comm, ticket):
+            self.comm, self.ticket = comm, ticket
+
+        def wait(self):
+            c = self.comm
+            c._lib.call("fb_slab_exchange_wait", c._plan, self.ticket, c._stream_fn())
+
+    def __init__(self, engine, world, rank, unique_id=None, stream_fn=None):
+        from . import _lib
+        self._lib, self._plan, self.world, self.rank = _lib, engine._plan, int(world), int(rank)
+        self._stream_fn = stream_fn or (lambda: engine.stream)
+        self._engine = engine                     # keeps the plan alive
+        if unique_id is not None and len(unique_id) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+        _lib.call("fb_comm_create", self._plan, self.world, self.rank, buf)
+
+    @staticmethod
+    def unique_id():
+        from . import _lib
+        buf = ctypes.create_string_buffer(128)
+        _lib.call("fb_comm_unique_id", buf)
+        return buf.raw
+
+    @classmethod
+    def from_environment(cls, engine, world, rank, stream_fn=None):
+        """Rank 0 draws the id, fastbox_amd.rendezvous hands it to the others (MASTER_ADDR / MASTER_PORT of the launcher)."""
+        from .rendezvous import broadcast_bytes
+        uid = broadcast_bytes(cls.unique_id() if rank == 0 else None, rank, world)
+        return cls(engine, world, rank, uid, stream_fn)
+
+    def info(self):
+        w, r, v = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        self._lib.call("fb_comm_info", self._plan, ctypes.byref(w), ctypes.byref(r), ctypes.byref(v))
+        return {"world": w.value, "rank": r.value, "rccl_version": v.value}
+
+    def all_to_all(self, rank, send, recv):
+        nbytes = send.numel() * send.element_size()
+        if nbytes % self.world or recv.numel() * recv.element_size() != nbytes:
+            raise ValueError("all-to-all of equal blocks: buffers of the same size, divisible by the number of ranks")
+        t = ctypes.c_int32()
+        self._lib.call("fb_slab_exchange_begin", self._plan, send.data_ptr(), recv.data_ptr(), nbytes // self.world,
+                       self._stream_fn(), ctypes.byref(t))
+        return RcclComm._Handle(self, t.value)
+
+    def all_reduce(self, rank, t, op="sum"):
+        if t.element_size() != 8 or not t.is_floating_point():
+            raise TypeError("fb_allreduce_f64 reduces float64 device arrays")
+        self._lib.call("fb_allreduce_f64", self._plan, t.data_ptr(), t.numel(), 0 if op == "sum" else 1, self._stream_fn())
+
+    def close(self):
+        if self._plan is not None:
+            self._lib.call("fb_comm_destroy", self._plan)
+            self._plan = None
+
+
 class VirtualComm(object):
     """The collectives of P SlabBox ranks that live in ONE process, each driven by its own thread (``run``): an all-to-all
     returns a handle at once, like an asynchronous collective; ``wait()`` of a rank's k-th collective blocks until every
@@ -693,14 +766,14 @@ class VirtualComm(object):
             self._posted.setdefault(k, [None] * self.P)[rank] = send
         return VirtualComm._Handle(self, rank, k, recv)
 
-    def all_reduce(self, rank, t):
+    def all_reduce(self, rank, t, op="sum"):
         with self._lock:
             self._red.setdefault("cur", [None] * self.P)[rank] = t
         self._meet()
         parts = self._red["cur"]
         total = parts[0].clone()
-        for q in range(1, self.P):
-            total += parts[q]                              # the same order on every rank
+        for q in range(1, self.P):                         # the same order on every rank
+            total = total + parts[q] if op == "sum" else total.maximum(parts[q])
         self._meet()
         t.copy_(total)
         self._meet()

@@ -39,6 +39,7 @@ extern "C" {
 #define FB_ERR_UNSUPPORTED -3  /* grid size not a power of two 16..2048 */
 #define FB_ERR_NOMEM -4
 #define FB_ERR_STATE -5        /* tables not set before use           */
+#define FB_ERR_RCCL -6         /* RCCL missing or a collective failed (fb_comm_*, fb_slab_exchange*, fb_allreduce_f64) */
 
 typedef struct fb_plan fb_plan;
 
@@ -346,6 +347,32 @@ int fb_slab_z_pass(fb_plan* plan, void* half_local, void* real_local, int nparts
  * the last call */
 int fb_slab_x_bin_chunk(fb_plan* plan, void* kchunk, int nparts, int part, int tile0, int ntile, int first, int last,
                         double* results_dev, void* stream);
+
+/* ---- one box over several GPUs: communicator (RCCL over xGMI) --------------------------------------------------
+ * The collectives of the slab-decomposed transform -- the all-to-all of equal blocks between the x-slab and the k_y-slab
+ * layout (ONE per transform: fastbox/box.py:187 ifftn, :193 / :736 fftn), the all-reduce of the 2 nbins + 1 bin sums
+ * (box.py:741-764) and of a field maximum -- behind the C ABI, so that a consumer of libfastbox_hip.so needs neither
+ * PyTorch nor an MPI to run one box over the GPUs of a node: one process (or thread) per GPU, each with its own plan.
+ *     rank 0:      fb_comm_unique_id(id);  hand the 128 bytes to the other ranks (file, socket, MPI_Bcast, ...)
+ *     every rank:  fb_comm_create(plan, world, rank, id);
+ *     per transform (or per k_z chunk):  fb_slab_x_generate[_chunk] -> fb_slab_exchange_begin -> ... the passes of the next
+ *                  chunk on the caller's stream ... -> fb_slab_exchange_wait -> fb_slab_y_inverse_chunk / _inverse_packed
+ *     fb_allreduce_f64(plan, results_dev, 2 * nbins + 1, 0, stream);   fb_comm_destroy(plan)   (fb_plan_destroy does it too)
+ * The exchange runs on a stream the communicator owns (event hand-off from and to the caller's stream: the host never
+ * blocks, and the caller's stream keeps computing between begin and wait); at most 16 exchanges in flight.  librccl is
+ * opened on the first of these calls (FASTBOX_RCCL_LIB overrides the name); failures are FB_ERR_RCCL with RCCL's own message.
+ * world = 1 with id = NULL needs no RCCL at all (the block moves by a device copy); world = 1 WITH an id makes a real
+ * one-rank RCCL communicator.  fastbox_amd.distributed.RcclComm / SlabBox(comm="rccl") drive it from Python (ctypes). */
+int fb_comm_unique_id(void* id128);                                   /* 128 bytes out                              */
+int fb_comm_create(fb_plan* plan, int world, int rank, const void* id128);
+int fb_comm_destroy(fb_plan* plan);
+int fb_comm_info(const fb_plan* plan, int* world, int* rank, int* rccl_version);   /* world 0: no communicator     */
+/* block q of send (bytes_per_peer bytes) -> rank q; block q of recv <- rank q; send != recv; ordered after `stream` */
+int fb_slab_exchange_begin(fb_plan* plan, const void* send, void* recv, int64_t bytes_per_peer, void* stream, int* ticket);
+int fb_slab_exchange_wait(fb_plan* plan, int ticket, void* stream);   /* `stream` waits for that exchange           */
+int fb_slab_exchange(fb_plan* plan, const void* send, void* recv, int64_t bytes_per_peer, void* stream);   /* begin + wait */
+/* in place on the device, in stream order; op 0 = sum, 1 = max */
+int fb_allreduce_f64(fb_plan* plan, double* data_dev, int count, int op, void* stream);
 
 /* The y and z passes of a transform run x-plane batch by x-plane batch so that a batch stays in the 256 MiB Infinity
  * Cache between them.  planes = -1: sized for ONE box using the GPU (default); when several boxes run concurrently on

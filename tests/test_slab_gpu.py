@@ -164,6 +164,70 @@ def test_rccl_backend_single_rank_collectives():
         dist.destroy_process_group()
 
 
+def test_library_communicator_on_one_rank():
+    """The exchange behind the C ABI (fb_comm_create, fb_slab_exchange_begin / _wait, fb_allreduce_f64: RCCL on a stream the
+    library owns, event hand-off with the compute stream) -- only one rank can run on this pool: a real one-rank RCCL
+    communicator (ncclSend / ncclRecv to itself inside a group, ncclAllReduce), the RCCL-free one-rank form, the tickets'
+    bounds, the state errors, and SlabBox(comm="rccl") against the torch.distributed path."""
+    import torch
+    from fastbox_amd import _lib, default_cosmo
+    from fastbox_amd._lib import FastBoxError
+    from fastbox_amd.distributed import RcclComm, SlabBox
+    box = SlabBox(default_cosmo, box_scale=1e3, nsamp=64, precision="f32", seed=3, device=0, rank=0, world=1)
+    eng, stream = box.ops.engine, box.ops._stream
+    x = torch.arange(1 << 16, dtype=torch.float32, device="cuda")
+    y = torch.zeros_like(x)
+    with pytest.raises(FastBoxError) as ei:                       # no communicator yet
+        _lib.call("fb_slab_exchange", eng._plan, x.data_ptr(), y.data_ptr(), x.numel() * 4, stream())
+    assert ei.value.code == -5
+    try:
+        uid = RcclComm.unique_id()
+    except FastBoxError as e:                                     # no librccl in this environment: FB_ERR_RCCL, loudly
+        assert e.code == -6
+        pytest.skip("RCCL unavailable: %s" % e)
+    assert len(uid) == 128
+    comm = RcclComm(eng, 1, 0, uid, stream)
+    info = comm.info()
+    assert info["world"] == 1 and info["rank"] == 0 and info["rccl_version"] > 0
+    with pytest.raises(FastBoxError) as ei:                       # one communicator per plan
+        RcclComm(eng, 1, 0, uid, stream)
+    assert ei.value.code == -5
+    handles = []
+    outs = [torch.zeros_like(x) for _ in range(3)]
+    for k, o in enumerate(outs):                                  # three exchanges in flight, waited in another order
+        handles.append(comm.all_to_all(0, x * (k + 1), o))
+    for h in (handles[2], handles[0], handles[1]):
+        h.wait()
+    torch.cuda.synchronize()
+    for k, o in enumerate(outs):
+        assert torch.equal(o, x * (k + 1))
+    with pytest.raises(FastBoxError):                             # a ticket that was never issued
+        _lib.call("fb_slab_exchange_wait", eng._plan, 1000, stream())
+    with pytest.raises(FastBoxError):                             # in place is refused
+        _lib.call("fb_slab_exchange", eng._plan, x.data_ptr(), x.data_ptr(), x.numel() * 4, stream())
+    r = torch.arange(41, dtype=torch.float64, device="cuda")
+    comm.all_reduce(0, r)
+    comm.all_reduce(0, r, op="max")
+    torch.cuda.synchronize()
+    assert torch.equal(r, torch.arange(41, dtype=torch.float64, device="cuda"))
+    comm.close()
+    # the RCCL-free one-rank form: a device copy on the communicator's stream
+    _lib.call("fb_comm_create", eng._plan, 1, 0, None)
+    y.zero_()
+    _lib.call("fb_slab_exchange", eng._plan, x.data_ptr(), y.data_ptr(), x.numel() * 4, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    _lib.call("fb_comm_destroy", eng._plan)
+    # the public class on the library's communicator
+    want = box.realise_and_power(nbins=20, lognormal=True)
+    box2 = SlabBox(default_cosmo, box_scale=1e3, nsamp=64, precision="f32", seed=3, device=0, rank=0, world=1, comm="rccl")
+    assert isinstance(box2._comm, RcclComm) and box2._comm.info()["rccl_version"] > 0
+    got = box2.realise_and_power(nbins=20, lognormal=True)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b, equal_nan=True)
+    box2._comm.close()
+
+
 @pytest.mark.parametrize("P", [1, 2])
 def test_slab_path_at_1024(P):
     """BASELINE config 4's size: the slab-decomposed field and its log-normal P(k) against the single-GPU box (whose
