@@ -78,6 +78,33 @@ class PendingSpectrum(object):
     def _in_range(self, s1, s2, esum):
         return hostgeom.lognormal_sums_in_range(self._cnt, s1, s2, esum)
 
+    @staticmethod
+    def _finish_batch(owners):
+        """The host arithmetic of `result()` for every record of one fetch at once (same numpy expressions, broadcast over
+        the records: identical numbers).  Records whose log-normal sums are out of range are left to `result()`, which
+        repeats the step."""
+        groups = {}
+        for o in owners:
+            if type(o) is PendingSpectrum and o._out is None and o._raw is not None:
+                groups.setdefault((o._nb, id(o._cnt), o._lnv, o._bf, _eps_of(o._eng)), []).append(o)
+        for (nb, _, lnv, bf, eps), grp in groups.items():
+            if len(grp) < 2:
+                continue
+            R = np.stack([o._raw for o in grp])
+            s1, s2, esum = R[:, 0:2 * nb:2], R[:, 1:2 * nb:2], R[:, 2 * nb]
+            cnt = grp[0]._cnt
+            good = np.ones(len(grp), dtype=bool)
+            with np.errstate(all="ignore"):
+                if lnv:
+                    good = hostgeom.lognormal_sums_in_range_many(cnt, s1, s2, esum)
+                    mean = esum / lnv
+                    s1, s2 = s1 / (mean ** 2)[:, None], s2 / (mean ** 4)[:, None]
+                vals, std = hostgeom.finish_bins_many(cnt, s1, s2, bf, eps)
+            for i, o in enumerate(grp):
+                if good[i]:
+                    o._out = (o._kc, vals[i].copy(), std[i].copy())
+                    o._res = o._keep = o._redo = None
+
     def result(self):
         if self._out is None:
             s1, s2, esum = self._eng.fetch_results(self._res, self._nb, owner=self)

@@ -129,6 +129,28 @@ def lognormal_sums_in_range(cnt, s1, s2, esum):
     return bool(np.all((a > 0.) | zero) and np.all(b * c[ok] >= a * a * (1. - 1e-3)))
 
 
+def lognormal_sums_in_range_many(cnt, s1, s2, esum):
+    """`lognormal_sums_in_range` for many records at once: s1, s2 (records, nbins), esum (records,) -> bool per record."""
+    c = np.asarray(cnt)[1:]
+    ok = c > 0
+    a, b = np.asarray(s1)[:, 1:][:, ok], np.asarray(s2)[:, 1:][:, ok]
+    with np.errstate(all="ignore"):
+        fin = np.isfinite(esum) & (esum > 0.) & np.all(np.isfinite(a), axis=1) & np.all(np.isfinite(b), axis=1)
+        zero = (a == 0.) & (b == 0.)
+        return fin & np.all((a > 0.) | zero, axis=1) & np.all(b * c[ok] >= a * a * (1. - 1e-3), axis=1)
+
+
+def finish_bins_many(cnt, s1, s2, boxfactor, eps=0.):
+    """`finish_bins` for many records at once (s1, s2: (records, nbins)); the same expressions, element for element."""
+    with np.errstate(all="ignore"):
+        vals = s1 / (cnt * boxfactor)
+        var = (s2 - s1 * s1 / cnt) / cnt
+        if eps:
+            var = np.where((cnt <= 2) & (var <= 4. * eps * (s1 / cnt) ** 2), 0., var)
+        stddev = np.sqrt(np.maximum(var, 0.)) / boxfactor / np.sqrt(cnt)
+    return vals[:, 1:], stddev[:, 1:]
+
+
 def bin_edges(g, nbins=20, kbins=None):
     """Edges and the centres of bins 1..nbins-1 (box.py:745-751)."""
     if kbins is not None:

@@ -75,3 +75,26 @@ def test_lognormal_range_check():
     assert not hostgeom.lognormal_sums_in_range(cnt, s1 * np.array([1, np.inf, 1, 1]), s2, 10.0)
     assert not hostgeom.lognormal_sums_in_range(cnt, s1, s2 * np.array([1, 1, 1, 0.5]), 10.0)   # squares flushed to zero
     assert hostgeom.lognormal_sums_in_range(cnt, s1 * np.array([np.inf, 1, 1, 1]), s2, 10.0)     # bin 0 is discarded
+
+
+def test_batched_spectrum_arithmetic_equals_the_scalar_path():
+    """hostgeom.finish_bins_many / lognormal_sums_in_range_many (what a batch of fetched records goes through) give the
+    numbers of the per-record functions bit for bit, NaN masks and out-of-range verdicts included."""
+    from fastbox_amd import hostgeom
+    rng = np.random.RandomState(3)
+    nb, m = 20, 37
+    cnt = np.array([0., 1., 2., 0.] + list(rng.randint(3, 5000, nb - 4)), dtype=np.float64)
+    s1 = rng.rand(m, nb) * cnt * 3.
+    s2 = (s1 / np.maximum(cnt, 1)) ** 2 * cnt * (1. + rng.rand(m, nb))
+    s1[:, cnt == 0] = 0.
+    s2[:, cnt == 0] = 0.
+    s2[:, 2] = s1[:, 2] ** 2 / 2. * (1. + 1e-8)          # a two-mode bin with (nearly) zero spread
+    esum = rng.rand(m) * 1e6 + 1.
+    s1[5, 7] = np.inf; s2[9, 6] *= 1e-3; esum[11] = 0.; s1[13, 8] = 0.; s2[13, 8] = 0.; s1[14, 9] = 0.
+    many_ok = hostgeom.lognormal_sums_in_range_many(cnt, s1, s2, esum)
+    vals, std = hostgeom.finish_bins_many(cnt, s1, s2, 0.37, 2. ** -23)
+    for i in range(m):
+        assert many_ok[i] == hostgeom.lognormal_sums_in_range(cnt, s1[i], s2[i], esum[i]), i
+        v, s = hostgeom.finish_bins(cnt, s1[i], s2[i], 0.37, 2. ** -23)
+        assert np.array_equal(v, vals[i], equal_nan=True) and np.array_equal(s, std[i], equal_nan=True), i
+    assert not many_ok[5] and not many_ok[9] and not many_ok[11] and many_ok[13] and not many_ok[14] and many_ok[0]

@@ -194,8 +194,9 @@ def test_library_communicator_on_one_rank():
     assert ei.value.code == -5
     handles = []
     outs = [torch.zeros_like(x) for _ in range(3)]
+    sends = [x * (k + 1) for k in range(3)]                       # (a send buffer belongs to the exchange until its wait)
     for k, o in enumerate(outs):                                  # three exchanges in flight, waited in another order
-        handles.append(comm.all_to_all(0, x * (k + 1), o))
+        handles.append(comm.all_to_all(0, sends[k], o))
     for h in (handles[2], handles[0], handles[1]):
         h.wait()
     torch.cuda.synchronize()
