@@ -615,10 +615,11 @@ class CosmoBox(object):
     # ---------------------------------------------------------------- redshift space
     def redshift_space_density(self, delta_x=None, velocity_z=None, sigma_nl=0., method='linear'):
         """Line-of-sight remap to redshift space (box.py:384-438).  ``method`` is what the reference hands to scipy's
-        ``griddata`` (box.py:433-437): 'linear' (default) and 'nearest' run on the device; 'cubic' (a spline through
-        every line of sight's shifted samples) does not."""
+        ``griddata`` (box.py:433-437), all three of its one-dimensional rules on the device: 'linear' (default), 'nearest', and
+        'cubic' -- the not-a-knot cubic spline through every line of sight's sorted shifted samples (what
+        ``griddata(method='cubic')`` = ``interp1d(kind='cubic')`` is in one dimension), the fill value outside them."""
         if method not in self.engine.RSD_METHODS:
-            raise NotImplementedError("method=%r: 'linear' and 'nearest' run on the device" % (method,))
+            raise ValueError("Unknown interpolation method %r for 1 dimensional data" % (method,))      # scipy's own refusal
         Hz = 100. * self.cosmo['h'] * _ccl.h_over_h0(self.cosmo, self.scale_factor)
         d = self._as_real(delta_x)
         v = self._as_real(velocity_z)
@@ -627,7 +628,7 @@ class CosmoBox(object):
             # the reference draws N normals per line of sight in (i, j) order (box.py:416-418)
             noise = self.engine.upload(np.random.normal(0., 1., (self.N, self.N, self.N)), REAL)
         seed = self.seed + 0x9E3779B97F4A7C15 * (self._realisation + 1)
-        if noise is None and self.engine.fuses_redshift_space:
+        if noise is None and method != "cubic" and self.engine.fuses_redshift_space:
             lazy = RedshiftSpaceField(self.engine, d, v, (Hz, sigma_nl, seed, method))
             if lazy.fusable():
                 return lazy

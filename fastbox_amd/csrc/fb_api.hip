@@ -311,7 +311,7 @@ int fb_redshift_space(fb_plan* p, const void* delta, const void* vz, const void*
     FB_USE_DEVICE(p);
     FB_REQUIRE(Hz > 0, "Hz must be positive");
     FB_REQUIRE(out != delta && out != vz, "redshift_space is out of place");
-    FB_REQUIRE(method == FB_RSD_LINEAR || method == FB_RSD_NEAREST, "method: FB_RSD_LINEAR or FB_RSD_NEAREST");
+    FB_REQUIRE(method == FB_RSD_LINEAR || method == FB_RSD_NEAREST || method == FB_RSD_CUBIC, "method: FB_RSD_LINEAR, FB_RSD_NEAREST or FB_RSD_CUBIC");
     hipStream_t s = (hipStream_t)stream;
     return FB_DISPATCH(p, fbi_rsd_f32(p, delta, vz, noise, out, Hz, sigma_nl, seed, method, s),
                        fbi_rsd_f64(p, delta, vz, noise, out, Hz, sigma_nl, seed, method, s));

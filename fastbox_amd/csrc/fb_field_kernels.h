@@ -622,6 +622,13 @@ __global__ void k_slab_permute(const uint4* __restrict__ in, uint4* __restrict__
 // box.py:412-437, one workgroup per line of sight: s = z - (v + sigma n)/H, periodic wrap,
 // sort (s, delta) in LDS (bitonic), then for every grid point the scipy griddata/np.interp
 // rule: left bracket by bisection, slope*(x - x_lo) + y_lo, exact hit -> y, outside -> fill.
+// method 2 ('cubic', round 4): what griddata(method='cubic') is in one dimension -- interp1d(kind='cubic') =
+// make_interp_spline(k=3): THE not-a-knot cubic spline through the sorted (s, delta) pairs, the fill value outside
+// [min s, max s].  Second derivatives M_i from the tridiagonal system  h_{i-1} M_{i-1} + 2 (h_{i-1} + h_i) M_i + h_i M_{i+1} =
+// 6 (D_i - D_{i-1})  (h_i = s_{i+1} - s_i, D_i = (delta_{i+1} - delta_i) / h_i) with the end conditions "third derivative
+// continuous at s_1 and s_{n-2}" eliminated into its first and last row, solved by one thread (Thomas: 2 n dependent steps in
+// LDS; the spline is unique, so this is scipy's banded solve up to rounding); every thread then evaluates its grid points.
+// Equal abscissae make scipy raise; here they give non-finite values on that line.
 template <typename T>
 __global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise,
                       T* __restrict__ out, const double* __restrict__ zgrid, int N, double Hz, double sigma_nl,
@@ -629,6 +636,8 @@ __global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, con
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* key = reinterpret_cast<double*>(smem);   // [N]
     double* val = key + N;                            // [N]
+    [[maybe_unused]] double* M2 = val + N;            // [N]  cubic: second derivatives (the Thomas right-hand sides on the way)
+    [[maybe_unused]] double* cp = M2 + N;             // [N]  cubic: modified upper diagonal
     const long long los = blockIdx.x;
     const T* d = delta + los * N;
     const T* v = vz + los * N;
@@ -663,6 +672,57 @@ __global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, con
             __syncthreads();
         }
     const double fill = 0.5 * ((double)d[0] + (double)d[N - 1]);
+    if (nearest == 2) {
+        if (threadIdx.x == 0) {
+#pragma clang fp contract(off)
+            const int n = N;
+            auto h = [&](int i) { return key[i + 1] - key[i]; };
+            auto D = [&](int i) { return (val[i + 1] - val[i]) / (key[i + 1] - key[i]); };
+            // row 1 with M_0 = (1 + h0/h1) M_1 - (h0/h1) M_2 substituted
+            {
+                const double h0 = h(0), h1 = h(1);
+                const double b = 2.0 * (h0 + h1) + h0 + h0 * h0 / h1, c = h1 - h0 * h0 / h1;
+                cp[1] = c / b;
+                M2[1] = 6.0 * (D(1) - D(0)) / b;
+            }
+            for (int i = 2; i <= n - 2; ++i) {
+                const double a = h(i - 1), hi = h(i);
+                double b = 2.0 * (a + hi), c = hi, aa = a;
+                if (i == n - 2) {          // last row with M_{n-1} = (1 + h_{n-2}/h_{n-3}) M_{n-2} - (h_{n-2}/h_{n-3}) M_{n-3} substituted
+                    aa = a - hi * hi / a;
+                    b = 2.0 * (a + hi) + hi + hi * hi / a;
+                    c = 0.0;
+                }
+                const double den = b - aa * cp[i - 1];
+                cp[i] = c / den;
+                M2[i] = (6.0 * (D(i) - D(i - 1)) - aa * M2[i - 1]) / den;
+            }
+            for (int i = n - 3; i >= 1; --i) M2[i] = M2[i] - cp[i] * M2[i + 1];
+            {
+                const double r0 = h(0) / h(1), rn = h(n - 2) / h(n - 3);
+                M2[0] = (1.0 + r0) * M2[1] - r0 * M2[2];
+                M2[n - 1] = (1.0 + rn) * M2[n - 2] - rn * M2[n - 3];
+            }
+        }
+        __syncthreads();
+        for (int m = threadIdx.x; m < N; m += blockDim.x) {
+#pragma clang fp contract(off)
+            const double x = zgrid[m];
+            double y;
+            if (x < key[0] || x > key[N - 1]) y = fill;
+            else {
+                int lo = 0, hi = N;                        // count of key[] <= x
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[mid] <= x) lo = mid + 1; else hi = mid; }
+                int jx = lo - 1;
+                if (jx > N - 2) jx = N - 2;                // x == key[N - 1]: the last interval
+                const double hh = key[jx + 1] - key[jx], A = key[jx + 1] - x, B = x - key[jx];
+                y = M2[jx] * (A * A * A) / (6.0 * hh) + M2[jx + 1] * (B * B * B) / (6.0 * hh)
+                  + (val[jx] / hh - M2[jx] * hh / 6.0) * A + (val[jx + 1] / hh - M2[jx + 1] * hh / 6.0) * B;
+            }
+            out[los * N + m] = (T)y;
+        }
+        return;
+    }
     for (int m = threadIdx.x; m < N; m += blockDim.x) {
 #pragma clang fp contract(off)
         const double x = zgrid[m];

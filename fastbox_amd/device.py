@@ -478,7 +478,7 @@ class Engine(object):
         _lib.call("fb_lognormal", self._plan, real.ptr, out.ptr, ctypes.byref(mean), self.stream)
         return out, mean.value
 
-    RSD_METHODS = {"linear": 0, "nearest": 1}       # FB_RSD_LINEAR, FB_RSD_NEAREST
+    RSD_METHODS = {"linear": 0, "nearest": 1, "cubic": 2}       # FB_RSD_LINEAR, FB_RSD_NEAREST, FB_RSD_CUBIC
 
     def redshift_space(self, delta, vz, Hz, sigma_nl=0.0, noise=None, seed=0, method="linear"):
         out = self.empty(REAL)

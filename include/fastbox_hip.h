@@ -191,10 +191,13 @@ int fb_lognormal(fb_plan* plan, const void* real_in, void* real_out, double* mea
 int fb_max_real(fb_plan* plan, const void* real, double* out, void* stream);
 /* redshift_space_density (box.py:405-437). noise: T[N][N][N] standard normals in LOS order
  * (parity) or NULL -> Philox stream 1 of `seed` when sigma_nl > 0.  method: what box.py:433-437 hands to
- * scipy's griddata -- 'linear' (the default; points outside the shifted samples get the end-point average)
- * or 'nearest' (no fill: scipy extrapolates with the end samples).                                        */
+ * scipy's griddata -- 'linear' (the default; points outside the shifted samples get the end-point average),
+ * 'nearest' (no fill: scipy extrapolates with the end samples) or 'cubic' (the not-a-knot cubic spline through the
+ * sorted shifted samples, the end-point average outside them; a line with two EQUAL shifted coordinates -- scipy raises
+ * there -- comes back non-finite).                                                                          */
 #define FB_RSD_LINEAR 0
 #define FB_RSD_NEAREST 1
+#define FB_RSD_CUBIC 2        /* griddata(method='cubic') in 1-D: the not-a-knot cubic spline through the sorted shifted samples */
 int fb_redshift_space(fb_plan* plan, const void* delta, const void* vz, const void* noise, void* out,
                       double Hz, double sigma_nl, uint64_t seed, int method, void* stream);
 /* sum(x) / sum(x^2) over a real field; sum |dk|^2 over the FULL grid from a half spectrum

@@ -307,11 +307,25 @@ def _regrid_nearest_1d(s, values, xi):
     return y[k]
 
 
+def _regrid_cubic_1d(s, values, z, fill):
+    """griddata(points=(s,), values, xi=(z,), method='cubic', fill_value=fill) in one dimension (box.py:433-437; scipy
+    interpolate/_ndgriddata.py: argsort, then interp1d(kind='cubic', bounds_error=False, fill_value=fill)): the not-a-knot
+    cubic spline through the sorted samples, `fill` outside [min s, max s].  Restated with CubicSpline(bc_type='not-a-knot')
+    -- the same spline by another of scipy's routes (they agree to 1e-15 here; pinned against the reference's own call in
+    tests/golden: rsd0_cubic)."""
+    from scipy.interpolate import CubicSpline
+    idx = np.argsort(s)
+    cs = CubicSpline(s[idx], values[idx], bc_type='not-a-knot', extrapolate=False)
+    y = cs(z)
+    y[np.isnan(y)] = fill
+    return y
+
+
 def redshift_space_density(g, delta_x, velocity_z, Hz, sigma_nl=0.,
                            rng=np.random, method='linear'):
     """Per line of sight (i,j): s = z - (v_z + sigma_nl n)/H, periodic wrap,
     re-grid delta(s) on z; endpoint-average fill.  Noise is drawn LOS by LOS in
-    (i,j) order from the legacy global stream (box.py:412-418).  method: 'linear' or 'nearest' (box.py:433-437)."""
+    (i,j) order from the legacy global stream (box.py:412-418).  method: 'linear', 'nearest' or 'cubic' (box.py:433-437)."""
     z = g['z']
     out = np.zeros_like(delta_x) - 1.
     zmin = np.min(z)
@@ -326,6 +340,8 @@ def redshift_space_density(g, delta_x, velocity_z, Hz, sigma_nl=0.,
             fill = 0.5 * (delta_x[i, j, 0] + delta_x[i, j, -1])
             if method == 'nearest':
                 out[i, j, :] = _regrid_nearest_1d(s, delta_x[i, j, :], z)
+            elif method == 'cubic':
+                out[i, j, :] = _regrid_cubic_1d(s, delta_x[i, j, :], z, fill)
             else:
                 out[i, j, :] = _regrid_linear_1d(s, delta_x[i, j, :], z, fill)
     return out

@@ -130,6 +130,9 @@ def capture(ref, name, N, box_scale, redshift, seed, s, what):
         # the other regridding rule box.py:433-437 accepts (sigma_nl = 0: no draw, the stream stays where it is)
         out["rsd0_nearest"] = probe(box.redshift_space_density(delta_x=box.delta_x, velocity_z=vz, sigma_nl=0.,
                                                                method='nearest'), s)
+        if N <= 64:      # griddata's third one-dimensional rule (round 4): N^2 spline fits by the reference, small cases only
+            out["rsd0_cubic"] = probe(box.redshift_space_density(delta_x=box.delta_x, velocity_z=vz, sigma_nl=0.,
+                                                                 method='cubic'), s)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("wrote", name, "(%d arrays)" % len(out))
 

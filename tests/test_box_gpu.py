@@ -177,8 +177,16 @@ def test_redshift_space_fp64(golden_dir, name):
     assert _field_close(p(rsd200), g["rsd200"], 1e-9)
     near = box.redshift_space_density(delta_x=dx, velocity_z=vz, sigma_nl=0., method='nearest')   # box.py:433-437
     assert _field_close(p(near), g["rsd0_nearest"], 1e-9)
-    with pytest.raises(NotImplementedError):
-        box.redshift_space_density(delta_x=dx, velocity_z=vz, method='cubic')
+    with pytest.raises(ValueError):                      # scipy refuses anything else for one-dimensional data
+        box.redshift_space_density(delta_x=dx, velocity_z=vz, method='quintic')
+    if "rsd0_cubic" in g.files:
+        # griddata(method='cubic') (box.py:433-437) = the not-a-knot cubic spline through each line's sorted shifted samples:
+        # against the reference's own output.  The spline amplifies: where two shifted samples nearly coincide it overshoots
+        # by orders of magnitude (n16_cube: values up to 1e3 from a field of rms 2.7), and the tridiagonal solve here and
+        # scipy's banded one round differently there -- hence a tolerance on the scale of the LARGEST value, 1e-9.
+        cub = box.redshift_space_density(delta_x=dx, velocity_z=vz, sigma_nl=0., method='cubic')
+        dev = np.max(np.abs(p(cub) - g["rsd0_cubic"])) / np.max(np.abs(g["rsd0_cubic"]))
+        assert dev <= 1e-9, dev
     kc, pk, err = box.binned_power_spectrum(delta_x=rsd0)
     assert _pk_close((pk,), (g["pkrsd_p"],), 1e-9)
     # BASELINE configs[2]: the wedge-filtered redshift-space field and its P(k), fused route (filter and binning inside
@@ -193,6 +201,42 @@ def test_redshift_space_fp64(golden_dir, name):
     assert np.allclose(pk[m], g["pkrsdw_p"][m], rtol=1e-9, atol=1e-12 * top)
     assert np.allclose(err[m], g["pkrsdw_e"][m], rtol=1e-7, atol=1e-12 * top)
     assert _field_close(p(filt), g["rsd_wedge"], 1e-9)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("N,vscale,noise", [(16, 30., 0.), (128, 40., 0.), (128, 400., 150.), (512, 60., 0.)])
+def test_redshift_space_cubic_spline_against_the_oracle(N, vscale, noise, precision):
+    """method='cubic' at sizes the goldens do not reach, with sub-cell shifts, wraps, and the small-scale velocity noise drawn on
+    the host (rng='numpy': the reference's stream), both plans: the device's sort + tridiagonal solve + evaluation against the
+    oracle's scipy spline on the same inputs (the single-precision plan holds its inputs in float32 and rounds its output).
+    Lines where two shifted samples fall within 1e-6 of a cell of each other are left out: there the spline's own condition
+    number, not the solver, decides the digits."""
+    from fastbox_amd import CosmoBox, default_cosmo
+    if precision == "f32" and noise > 0.:
+        pytest.skip("the single-precision plan holds the host-drawn noise in float32: not the oracle's inputs")
+    rng = np.random.RandomState(7)
+    L = 3e2
+    box = CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, precision=precision)
+    geo = bo.box_geometry(L, N)
+    nl = N if N <= 128 else 24                       # the oracle fits one spline per line: a slab of the box at 512
+    d = rng.normal(size=(N, N, N))
+    v = vscale * rng.normal(size=(N, N, N))
+    if precision == "f32":
+        d, v = d.astype(np.float32).astype(np.float64), v.astype(np.float32).astype(np.float64)
+    Hz = standin.hubble(standin.cosmology(), 1.0)
+    np.random.seed(3)
+    got = np.asarray(box.redshift_space_density(delta_x=d, velocity_z=v, sigma_nl=noise, method='cubic'))[:nl]
+    want = bo.redshift_space_density(geo, d[:nl], v[:nl], Hz, noise, np.random.RandomState(3), method='cubic')
+    # the lines' shifted coordinates (as the oracle forms them) to find the ill-conditioned ones
+    z = geo['z']
+    vel = v[:nl] + (noise * np.random.RandomState(3).normal(0., 1., (nl, N, N)) if noise > 0. else 0.)
+    srt = np.sort((z - vel / Hz - z.min()) % (z.max() - z.min()) + z.min(), axis=-1)
+    ok = np.min(np.diff(srt, axis=-1), axis=-1) > 1e-6 * (z[1] - z[0])
+    assert ok.mean() > 0.9
+    tol = 1e-9 if precision == "f64" else 3e-6
+    scale = np.max(np.abs(want[ok]), axis=-1, keepdims=True)
+    assert np.max(np.abs(got[ok] - want[ok]) / scale) < tol, np.max(np.abs(got[ok] - want[ok]) / scale)
+    assert np.all(np.isfinite(got[ok]))
 
 
 @pytest.mark.parametrize("N,vscale", [(128, 0.), (128, 40.), (256, 3e4)])

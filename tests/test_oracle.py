@@ -93,6 +93,9 @@ def test_derived_fields(golden_dir, name):
     rsd0 = bo.redshift_space_density(geo, dx, vz, Hz, 0.)
     assert _same(p(rsd0), g["rsd0"])
     assert _same(p(bo.redshift_space_density(geo, dx, vz, Hz, 200., rng)), g["rsd200"])
+    if "rsd0_cubic" in g.files:      # griddata's third 1-D rule: the restatement builds the same not-a-knot spline by another scipy route
+        cub = p(bo.redshift_space_density(geo, dx, vz, Hz, 0., method='cubic'))
+        assert np.max(np.abs(cub - g["rsd0_cubic"])) <= 1e-11 * np.max(np.abs(g["rsd0_cubic"]))
     kc, pk, err = bo.binned_power_spectrum(geo, np.fft.fftn(rsd0))
     assert _same(pk, g["pkrsd_p"])
     # BASELINE configs[2]: wedge-filtered redshift-space field and its P(k)
