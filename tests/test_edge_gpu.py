@@ -57,8 +57,12 @@ def test_interface_errors_and_limits():
         _box(N=48)                                   # not a power of two: refused, no fallback
     with pytest.raises(FastBoxError):
         _box(N=8)
-    with pytest.raises(NotImplementedError):
-        box.redshift_space_density(delta_x=np.zeros((32,) * 3), velocity_z=np.zeros((32,) * 3), method="cubic")
+    with pytest.raises(ValueError):                  # scipy's griddata knows 'nearest', 'linear', 'cubic' for 1-D data
+        box.redshift_space_density(delta_x=np.zeros((32,) * 3), velocity_z=np.zeros((32,) * 3), method="quintic")
+    # method='cubic' with v = 0: the last sample wraps onto the first, two EQUAL abscissae -- scipy's spline raises
+    # ("Expect x to not have duplicates"); the device marks such a line as not-a-number instead (fastbox_hip.h)
+    flat = np.asarray(box.redshift_space_density(delta_x=np.ones((32,) * 3), velocity_z=np.zeros((32,) * 3), method="cubic"))
+    assert not np.all(np.isfinite(flat))
     with pytest.raises(ValueError):
         box.binned_power_spectrum(delta_x=np.zeros((16,) * 3))      # wrong shape
     with pytest.raises(AttributeError):
