@@ -258,7 +258,9 @@ def _make_boxes(args, N, precision, n, rank, local_rank):
     # (512^3 fp32, two boxes: 64 planes = 2 x 70 MB of half spectrum + real planes; measured in profiles/r02_*)
     sz = 4 if precision == "f32" else 8
     plane_bytes = (N + 1) * ((N // 2 + 16) // 16 * 16) * 2 * sz + N * N * sz       # half-spectrum plane + real plane
-    share = max(4, int(280e6 / max(1, n) / plane_bytes))
+    # (2048^3, single precision: the y passes run in 128-byte rows, 64 tiles per plane, and want >= 16 planes per launch:
+    # 12.1 boxes/s against 11.8 with 4, profiles/r04_pass_bench_2048.txt)
+    share = max(16 if (N >= 2048 and precision == "f32") else 4, int(280e6 / max(1, n) / plane_bytes))
     pb = args.plane_batch if args.plane_batch is not None else (-1 if n == 1 or share >= N else share)
     ps = args.plane_streams if args.plane_streams is not None else (0 if n == 1 else 1)
     for b in boxes:

@@ -312,7 +312,11 @@ class CosmoBox(object):
         if rng not in ("numpy", "device"):
             raise ValueError("rng must be 'numpy' or 'device'")
         self.rng, self.seed, self._realisation = rng, int(seed), 0
-        self._cubic = (self.Lx == self.Ly == self.Lz)
+        # grids that are not powers of two (round 4: even, prime factors 2, 3, 5, up to 1024 -- numpy's FFT takes any nsamp,
+        # box.py:25-26): the library's plain FFT passes; nothing is fused into them, so such a box takes the step-by-step
+        # routes a non-cubic box takes (exact |k| per mode instead of shell tables, stored spectra)
+        self._plain = (self.N & (self.N - 1)) != 0
+        self._cubic = (self.Lx == self.Ly == self.Lz) and not self._plain
         self._grids = None
         self._amp_key = None
         self._bin_cache = {}
@@ -333,7 +337,7 @@ class CosmoBox(object):
         (N,N,N) arrays Kx, Ky, Kz, k of the reference are never built on the device; the
         attributes of the same name materialise them on the host on first access."""
         N = self.N
-        m = (N * np.fft.fftfreq(N, 1.)).astype("i").astype(np.float64)
+        m = hostgeom.mode_numbers(N)        # the reference's own numbering, index-as-value quirk at non-powers of two included
         self._modes = m
         L = (self.Lx, self.Ly, self.Lz)
         self._axis2 = np.concatenate([(m / l) ** 2. for l in L])
@@ -475,6 +479,12 @@ class CosmoBox(object):
             del re, im
             delta_x = eng.fft_c2r(half, destroy=True)
             delta_x.sigma2 = self._sigma2
+        elif self._plain:
+            # no fused generator pass on such a grid: the coloured half spectrum (same counters, same numbers), then c2r
+            delta_x = eng.fft_c2r(eng.colour_device(self.seed, self._realisation), destroy=True)
+            delta_x.sigma2 = self._sigma2
+            self.last_realisation = self._realisation
+            self._realisation += 1
         else:
             # generator fused into the first inverse FFT pass (no coloured spectrum round trip); the
             # last pass is deferred so that a following P(k) can fuse it with its own first pass

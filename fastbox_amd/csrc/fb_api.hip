@@ -95,13 +95,23 @@ int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int p
     FB_REQUIRE(plan && axis2 && ksc && kpar && zgrid, "null pointer");
     FB_REQUIRE(precision == 4 || precision == 8, "precision must be 4 or 8");
     FB_REQUIRE(Lx > 0 && Ly > 0 && Lz > 0, "box sides must be positive");
-    if (N < 16 || N > 2048 || (N & (N - 1))) {
-        fb_set_error("unsupported grid size: nsamp must be a power of two in 16..2048");
+    // powers of two 16 .. 2048: the tuned kernels.  Other EVEN sizes whose prime factors are 2, 3, 5, up to 1024 (round 4): the
+    // generic FFT passes (fb_fft_generic.h) behind fb_fft_c2c / _r2c / _c2r and every kernel that is not an FFT pass; the entry
+    // points that fuse something into an FFT pass return FB_ERR_UNSUPPORTED on such a plan.
+    bool pow2 = N >= 16 && N <= 2048 && !(N & (N - 1)), smooth = false;
+    if (!pow2 && N >= 16 && N <= 1024 && N % 2 == 0) {
+        int q = N;
+        for (int f : {2, 3, 5}) while (q % f == 0) q /= f;
+        smooth = q == 1;
+    }
+    if (!pow2 && !smooth) {
+        fb_set_error("unsupported grid size: nsamp must be a power of two in 16..2048, or even with prime factors 2, 3, 5 in 16..1024");
         return FB_ERR_UNSUPPORTED;
     }
     FB_HIP(hipSetDevice(device));
     fb_plan* p = new fb_plan();
     p->N = N; p->prec = precision; p->device = device;
+    p->generic = pow2 ? 0 : 1;
     p->L[0] = Lx; p->L[1] = Ly; p->L[2] = Lz;
     p->cubic = (Lx == Ly && Ly == Lz);
     {

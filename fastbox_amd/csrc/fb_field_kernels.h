@@ -632,12 +632,14 @@ __global__ void k_slab_permute(const uint4* __restrict__ in, uint4* __restrict__
 template <typename T>
 __global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, const T* __restrict__ noise,
                       T* __restrict__ out, const double* __restrict__ zgrid, int N, double Hz, double sigma_nl,
-                      RngKey rkey, int nearest) {
+                      RngKey rkey, int nearest, int N2) {
+    // N2: N rounded up to a power of two -- the length of the sorting network (grids that are not powers of two: the
+    // extra keys are +infinity and stay behind the N real ones)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* key = reinterpret_cast<double*>(smem);   // [N]
-    double* val = key + N;                            // [N]
-    [[maybe_unused]] double* M2 = val + N;            // [N]  cubic: second derivatives (the Thomas right-hand sides on the way)
-    [[maybe_unused]] double* cp = M2 + N;             // [N]  cubic: modified upper diagonal
+    double* key = reinterpret_cast<double*>(smem);   // [N2]
+    double* val = key + N2;                           // [N2]
+    [[maybe_unused]] double* M2 = val + N2;           // [N]  cubic: second derivatives (the Thomas right-hand sides on the way)
+    [[maybe_unused]] double* cp = M2 + N2;            // [N]  cubic: modified upper diagonal
     const long long los = blockIdx.x;
     const T* d = delta + los * N;
     const T* v = vz + los * N;
@@ -658,11 +660,12 @@ __global__ void k_rsd(const T* __restrict__ delta, const T* __restrict__ vz, con
         key[m] = r + zmin;
         val[m] = (double)d[m];
     }
+    for (int m = N + threadIdx.x; m < N2; m += blockDim.x) { key[m] = __builtin_huge_val(); val[m] = 0.0; }
     __syncthreads();
-    for (int k = 2; k <= N; k <<= 1)
+    for (int k = 2; k <= N2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             // one compare-exchange per thread and step: pair q -> (m, m | j) with bit j of m clear
-            for (int q = threadIdx.x; q < (N >> 1); q += blockDim.x) {
+            for (int q = threadIdx.x; q < (N2 >> 1); q += blockDim.x) {
                 const int m = ((q & ~(j - 1)) << 1) | (q & (j - 1));
                 const int p = m | j;
                 const bool up = (m & k) == 0;

@@ -18,6 +18,7 @@ struct fb_comm;                  // fb_comm.inc: RCCL communicator + its stream 
 struct fb_plan {
     fb_comm* comm = nullptr;     // one box over several GPUs: this rank's communicator, or null
     int N = 0;
+    int generic = 0;         // 1: N is not a power of two (even, factors 2, 3, 5, <= 1024): the plain passes of fb_fft_generic.h, no fused entry points
     int prec = 4;            // bytes per real: 4 (float) or 8 (double)
     double L[3] = {0, 0, 0};
     int device = 0;

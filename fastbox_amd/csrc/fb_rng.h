@@ -120,7 +120,7 @@ __device__ __forceinline__ ModeDraw mode_draw(int ix, int iy, int iz, int N) {
         const bool ys = (iy == 0 || iy == H), xs = (ix == 0 || ix == H);
         d.real_only = ys && xs;
         d.conj = ys ? (ix > H) : (iy > H);
-        if (d.conj) { d.ix = (N - ix) & (N - 1); d.iy = (N - iy) & (N - 1); }
+        if (d.conj) { d.ix = ix ? N - ix : 0; d.iy = iy ? N - iy : 0; }      // (N - i) mod N, any even N
     }
     return d;
 }
@@ -130,7 +130,7 @@ template <typename T>
 __device__ __forceinline__ void mode_noise(int ix, int iy, int iz, int N, int NZV, const RngKey& key, T s, T& re, T& im) {
     const ModeDraw d = mode_draw(ix, iy, iz, N);
     const int H = N >> 1;
-    const int g = d.ix & (H - 1);
+    const int g = d.ix >= H ? d.ix - H : d.ix;          // d.ix mod N/2 (d.ix < N)
     const unsigned long long idx = ((unsigned long long)g * N + d.iy) * NZV + iz;
     T a0, a1, b0, b1;
     stream_normals4<T>(idx, 0u, key, a0, a1, b0, b1);

@@ -24,8 +24,18 @@ def grid(box_scale, nsamp):
 
 
 def mode_numbers(N):
-    """box.py:119."""
-    return (N * np.fft.fftfreq(N, 1.)).astype("i").astype(np.float64)
+    """The integer mode number the reference's k grid carries at every index (box.py:119-123):
+
+        NN = (N * fftfreq(N, 1.)).astype("i");  for i in NN: Kx[i, :, :] = i
+
+    -- `i` is index AND value.  For a power of two the product is exact and this is fftfreq's numbering.  For other N the
+    product can round just below an integer (24 * (7/24) = 6.999...), the cast truncates, NN then holds 6 twice and 7 never,
+    and Kx[7] keeps the 0 it was initialised with.  Reproduced as it is: same inputs, same results as the reference."""
+    nn = (N * np.fft.fftfreq(N, 1.)).astype("i")
+    m = np.zeros(N, dtype=np.float64)
+    for i in nn:
+        m[i] = i
+    return m
 
 
 def axis_tables(N, L):

@@ -34,6 +34,7 @@ CASES = [
     ("n16_cuboid", 16, (1e2, 2e2, 1e3), 1.0, 11, 1, "all"),
     ("n32_l1000", 32, 1e3, 0.0, 14, 2, "all"),
     ("n64_l1000", 64, (1e3, 1e3, 1e3), 0.0, 14, 4, "all"),
+    ("n48_l1000", 48, 1e3, 0.0, 14, 4, "all"),          # a grid that is not a power of two (numpy's FFT takes any nsamp)
     ("n64_l100", 64, (1e2, 1e2, 1e2), 0.0, 11, 4, "pk"),
     ("n64_l4000", 64, 4e3, 0.8, 10, 4, "pk"),
     ("n128_l1000", 128, 1e3, 0.0, 14, 8, "pk"),

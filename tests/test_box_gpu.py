@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 FIELD_TOL = {"f32": 2e-5, "f64": 1e-11}
 PK_TOL = {"f32": 1e-5, "f64": 1e-11}
-CASES_ALL = ["n16_cube", "n16_cuboid", "n32_l1000", "n64_l1000", "n256_l1000"]
+CASES_ALL = ["n16_cube", "n16_cuboid", "n32_l1000", "n48_l1000", "n64_l1000", "n256_l1000"]
 CASES_PK = ["n64_l100", "n64_l4000", "n128_l1000"]
 
 

@@ -54,7 +54,7 @@ def test_interface_errors_and_limits():
     from fastbox_amd._lib import FastBoxError
     box = _box()
     with pytest.raises(FastBoxError):
-        _box(N=48)                                   # not a power of two: refused, no fallback
+        _box(N=34)                                   # a prime factor 17: refused, no fallback (2, 3, 5 only: test_generic_grid_gpu.py)
     with pytest.raises(FastBoxError):
         _box(N=8)
     with pytest.raises(ValueError):                  # scipy's griddata knows 'nearest', 'linear', 'cubic' for 1-D data

@@ -1,0 +1,130 @@
+"""GPU: grid sizes that are not powers of two (round 4: any even nsamp with prime factors 2, 3, 5 up to 1024 -- the
+reference's numpy FFT takes any nsamp, fastbox/box.py:25-26).  The library's plain FFT passes (fb_fft_generic.h) against numpy,
+and the CosmoBox methods -- which take the step-by-step routes on such a grid -- against the numpy oracle on the same seed."""
+import numpy as np
+import pytest
+
+from oracle import box_oracle as bo
+from oracle import standin
+
+pytestmark = pytest.mark.gpu
+
+FIELD_TOL = {"f32": 2e-5, "f64": 1e-11}
+PK_TOL = {"f32": 1e-5, "f64": 1e-11}
+
+
+def _rms(a):
+    return np.sqrt(np.mean(np.abs(a) ** 2))
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("N", [18, 24, 30, 48, 80, 96, 120, 250, 384, 1000])
+def test_plain_passes_against_numpy(N, precision):
+    from fastbox_amd import CosmoBox, default_cosmo
+    from fastbox_amd.device import FULL, REAL
+    if N >= 384 and precision == "f64":
+        pytest.skip("one precision is enough at the large sizes")
+    box = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False, precision=precision)
+    eng = box.engine
+    rng = np.random.RandomState(N)
+    tol = 3e-6 if precision == "f32" else 1e-13
+    x = rng.normal(size=(N, N, N))
+    half = eng.fft_r2c(eng.upload(x, REAL))
+    got = np.asarray(eng.expand_half(half))
+    want = np.fft.fftn(x)
+    assert np.max(np.abs(got - want)) < tol * _rms(want) * np.sqrt(np.log2(N ** 3))
+    back = np.asarray(eng.fft_c2r(half, destroy=True))
+    assert np.max(np.abs(back - x)) < tol * 10
+    if N <= 120:
+        c = rng.normal(size=(N, N, N)) + 1j * rng.normal(size=(N, N, N))
+        for direction, ref in ((-1, np.fft.fftn(c)), (+1, np.fft.ifftn(c) * N ** 3)):
+            out = np.asarray(eng.fft_c2c(eng.upload(c, FULL), direction, 1.0))
+            assert np.max(np.abs(out - ref)) < tol * _rms(ref) * np.sqrt(np.log2(N ** 3))
+
+
+def test_sizes_that_are_refused():
+    from fastbox_amd import CosmoBox, default_cosmo
+    from fastbox_amd._lib import FastBoxError
+    for N in (14, 34, 42, 1030, 1536, 27):           # too small, a factor 17 / 7, too large for the plain passes, odd
+        with pytest.raises(FastBoxError):
+            CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("N,L", [(24, 3e2), (48, 1e3), (80, (2e2, 3e2, 5e2)), (96, 1e3)])
+def test_cosmobox_on_a_grid_that_is_not_a_power_of_two(N, L, precision):
+    from fastbox_amd import BeamHighpass, CosmoBox, default_cosmo, Wedge
+    seed = 21
+    ftol, ptol = FIELD_TOL[precision], PK_TOL[precision]
+    np.random.seed(seed)
+    box = CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, precision=precision)
+    geo = bo.box_geometry(L, N)
+    cosmo = standin.cosmology()
+    re, im = bo.draw_noise(N, np.random.RandomState(seed))
+    odx, odk = bo.realise_density(geo, standin.pk_fn(cosmo, 1.0), re, im)
+    dx = box.realise_density()
+    assert np.max(np.abs(np.asarray(dx) - odx)) <= ftol * np.std(odx)
+    assert np.max(np.abs(np.asarray(box.delta_k) - odk)) <= ftol * _rms(odk)
+
+    def pk_close(got, want, tol):
+        for n, (a, b) in enumerate(zip(got, want)):
+            assert np.array_equal(np.isnan(a), np.isnan(b))
+            m = ~np.isnan(b)
+            floor = 0 if n == 0 else tol * np.abs(np.asarray(want[0])[m])
+            assert np.all(np.abs(a[m] - b[m]) <= tol * np.abs(b[m]) + floor), (n, np.max(np.abs(a[m] - b[m]) / (np.abs(b[m]) + 1e-300)))
+    for nb in (20, 12):
+        kc, pk, err = box.binned_power_spectrum(nbins=nb)
+        okc, opk, oerr = bo.binned_power_spectrum(geo, odk, nbins=nb)
+        assert np.array_equal(kc, okc)
+        pk_close((pk, err), (opk, oerr), ptol)
+    kc, pk, err = box.binned_power_spectrum(delta_x=box.lognormal(dx))
+    okc, opk, oerr = bo.binned_power_spectrum(geo, np.fft.fftn(bo.lognormal(odx)))
+    pk_close((pk, err), (opk, oerr), 3 * ptol if precision == "f32" else ptol)       # (exp amplifies delta's rounding; no golden here)
+    for fn in (standin.wedge03, Wedge(slope=0.3), BeamHighpass(kpar0=0.009, power=3.)):
+        ofn = fn if not isinstance(fn, BeamHighpass) else standin.highpass3
+        want = bo.apply_transfer_fn(geo, odk, ofn)
+        got = np.asarray(box.apply_transfer_fn(box.delta_k, fn))
+        assert np.max(np.abs(got - want)) <= 5 * ftol * _rms(want)
+    a = 1.0
+    vel = box.realise_velocity()
+    ovel = bo.realise_velocity(geo, odk, standin.velocity_fac(cosmo, a))
+    for c in range(3):
+        assert np.max(np.abs(np.asarray(vel[c]) - ovel[c])) <= 5 * ftol * _rms(ovel[c])
+    # (the reference's k grid has extra k = 0 modes on such a grid -- hostgeom.mode_numbers -- and delta_k / k^2 is infinite there,
+    # in the reference as here: box.py:347-348 zeroes the DC mode only)
+    ophi, phi = bo.realise_potential(geo, odk), np.asarray(box.realise_potential())
+    fin = np.isfinite(ophi)
+    assert np.array_equal(np.isfinite(phi), fin)
+    assert np.max(np.abs(phi[fin] - ophi[fin])) <= 5 * ftol * _rms(ophi[fin])
+    if precision == "f64":          # the remap is pinned in fp64 (its bracket search is discontinuous)
+        Hz = standin.hubble(cosmo, a)
+        ovz = np.fft.ifftn(ovel[2]).real
+        vz = box.to_real(vel[2])
+        for method in ("linear", "nearest", "cubic"):
+            want = bo.redshift_space_density(geo, odx, ovz, Hz, 0., method=method)
+            got = np.asarray(box.redshift_space_density(delta_x=dx, velocity_z=vz, sigma_nl=0., method=method))
+            if method == "nearest":
+                assert np.mean(np.abs(got - want) > 1e-9 * np.std(odx)) < 1e-4
+            else:
+                assert np.max(np.abs(got - want)) <= 1e-8 * np.max(np.abs(want)), method
+
+
+@pytest.mark.parametrize("N", [48, 160])
+def test_device_generator_on_a_grid_that_is_not_a_power_of_two(N):
+    """rng='device': the counter-based generator's field against the host model of its noise (fastbox_amd/rng.py)."""
+    from fastbox_amd import CosmoBox, default_cosmo, rng
+    L, seed = 1e3, 77
+    box = CosmoBox(cosmo=default_cosmo, box_scale=L, nsamp=N, realise_now=False, precision="f64", rng="device", seed=seed)
+    dx = np.asarray(box.realise_density())
+    geo = bo.box_geometry(L, N)
+    z = rng.half_spectrum_noise(N, seed, 0)
+    k = bo.k_magnitude(geo)[:, :, :N // 2 + 1]
+    pk_fn = standin.pk_fn(standin.cosmology(), 1.0)
+    with np.errstate(all="ignore"):
+        amp = np.sqrt(np.nan_to_num(pk_fn(k.flatten())).reshape(k.shape) * geo["boxfactor"])
+    want = np.fft.irfftn(z * amp, s=(N, N, N), axes=(0, 1, 2))
+    assert np.max(np.abs(dx - want)) <= 1e-10 * np.std(want)
+    kc, pk, err = box.binned_power_spectrum(delta_x=dx)
+    okc, opk, oerr = bo.binned_power_spectrum(geo, np.fft.fftn(want))
+    m = ~np.isnan(opk)
+    assert np.array_equal(kc, okc) and np.allclose(pk[m], opk[m], rtol=1e-10, atol=0)

@@ -8,7 +8,7 @@ import pytest
 from oracle import box_oracle as bo
 from oracle import standin
 
-CASES_ALL = ["n16_cube", "n16_cuboid", "n32_l1000", "n64_l1000", "n256_l1000"]
+CASES_ALL = ["n16_cube", "n16_cuboid", "n32_l1000", "n48_l1000", "n64_l1000", "n256_l1000"]
 CASES_PK = ["n64_l100", "n64_l4000", "n128_l1000"]
 
 
