@@ -80,8 +80,9 @@ def test_c2r_projects_non_hermitian_planes(precision):
 
 def test_unsupported_size_fails_loudly():
     from fastbox_amd._lib import FastBoxError
-    with pytest.raises(FastBoxError):
-        _engine(24, "f32")
+    for N in (22, 1026, 25):           # a prime factor 11, beyond the plain passes' range, odd (24, 48, ...: tests/test_generic_grid_gpu.py)
+        with pytest.raises(FastBoxError):
+            _engine(N, "f32")
 
 
 @pytest.mark.parametrize("precision,tol", [("f32", 2e-6), ("f64", 1e-12)])
