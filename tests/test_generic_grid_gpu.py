@@ -18,7 +18,7 @@ def _rms(a):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f64"])
-@pytest.mark.parametrize("N", [18, 24, 30, 48, 80, 96, 120, 250, 384, 1000])
+@pytest.mark.parametrize("N", [18, 24, 30, 48, 80, 96, 120, 250, 384, 500])
 def test_plain_passes_against_numpy(N, precision):
     from fastbox_amd import CosmoBox, default_cosmo
     from fastbox_amd.device import FULL, REAL
