@@ -75,6 +75,7 @@ SIGNATURES = {
     "fb_beam_convolve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fb_channel_means": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_channel_covariance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fb_leading_eigenvectors": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fb_pca_clean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "fb_sky_realise_map": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_double, c_void_p, c_void_p, c_void_p]),
     "fb_sky_normal_map": (c_int, [c_void_p, c_void_p, c_u64, c_double, c_double, c_void_p, c_void_p]),

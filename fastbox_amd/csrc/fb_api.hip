@@ -877,5 +877,6 @@ int fb_stream_wait_stream(void* waiter, void* signaller) {
 }
 
 #include "fb_comm.inc"
+#include "fb_eigen.inc"
 
 }  // extern "C"

@@ -4,11 +4,12 @@ Foreground cleaning of a data cube on the device: the step between "add foregrou
 Same function names, arguments and return values as fastbox/filters.py (:35-56, :93-183).
 
 The cube never leaves HBM: channel means, the frequency-frequency covariance (N^2 pixels x N x N
-channels, on the fp64 matrix cores) and the projection run in libfastbox_hip.  Only the N x N covariance
-comes to the host, for the eigen-decomposition (an N x N symmetric problem: numpy.linalg.eigh), and the
-nmodes leading eigenvectors go back.  The cleaned cube depends only on the span of those modes, so it
-equals the reference's (which uses the unsymmetric solver numpy.linalg.eig); individual eigenvectors and
-mode amplitudes may differ from the reference's by a sign.
+channels, on the fp64 matrix cores) and the projection run in libfastbox_hip.  The leading eigenvectors
+of the N x N covariance come from LAPACK on the host by default (the faster of the two for one small matrix)
+or, with `eigensolver="device"`, from fb_leading_eigenvectors (cyclic Jacobi in fp64 on the GPU: the route
+of a C-ABI consumer without LAPACK).  The cleaned cube depends only on the span of the modes, so it equals the reference's
+(which uses the unsymmetric solver numpy.linalg.eig); individual eigenvectors and mode amplitudes may
+differ from the reference's by a sign.
 """
 import ctypes
 
@@ -55,10 +56,15 @@ def mean_spectrum_filter(field, box=None):
     return out
 
 
-def pca_filter(field, nmodes, fit_powerlaw=False, return_filter=False, box=None):
+def pca_filter(field, nmodes, fit_powerlaw=False, return_filter=False, box=None, eigensolver="host"):
     """Remove the `nmodes` leading eigenmodes of the empirical frequency-frequency covariance
     (filters.py:93-183).  Returns the cleaned cube (DeviceArray) and, if `return_filter`, the mode matrix
-    U_fg (Nfreq, nmodes) and the amplitudes fg_amps (nmodes, Npix) as host arrays."""
+    U_fg (Nfreq, nmodes) and the amplitudes fg_amps (nmodes, Npix) as host arrays.
+    eigensolver: "host" (default: LAPACK dsyevr on the downloaded N x N covariance -- 6.5 ms at N = 512) or "device"
+    (fb_leading_eigenvectors: cyclic Jacobi in fp64 on the GPU, nothing leaves it and no LAPACK is needed -- 30 ms at
+    N = 512, profiles/r04_eigen_bench.txt).  The sign of a mode is not defined in either, as in the reference."""
+    if eigensolver not in ("device", "host"):
+        raise ValueError("eigensolver: 'device' or 'host'")
     cube = _as_cube(field, box)
     eng = cube.engine
     N = eng.N
@@ -79,17 +85,25 @@ def pca_filter(field, nmodes, fit_powerlaw=False, return_filter=False, box=None)
         mean = eng.upload_raw(np.ascontiguousarray(fn(freqs, pfit[0], pfit[1])))
     cov_dev = eng._alloc_bytes(N * N * 8)
     _lib.call("fb_channel_covariance", eng._plan, cube.ptr, mean_true.ptr, cov_dev.ptr, eng.stream)
-    cov = np.empty((N, N))
-    _lib.call("fb_memcpy_d2h", cov.ctypes.data_as(ctypes.c_void_p), cov_dev.ptr, cov.nbytes, eng.stream)
+    nmodes = int(nmodes)
+    if not 0 <= nmodes <= N:
+        raise ValueError("nmodes must lie in 0 .. %d" % N)
     # filters.py:161-169: eigenvectors by decreasing eigenvalue, keep nmodes
-    with _few_blas_threads():
-        if 0 < nmodes < N:
-            from scipy.linalg import eigh      # only the nmodes largest eigenpairs (LAPACK dsyevr)
-            w, v = eigh(cov, subset_by_index=[N - nmodes, N - 1])
-        else:
-            w, v = np.linalg.eigh(cov)
-    U_fg = np.ascontiguousarray(v[:, ::-1][:, :nmodes])
-    U_dev = eng.upload_raw(U_fg)
+    U_fg = None
+    if eigensolver == "device":
+        U_dev = eng._alloc_bytes(max(1, nmodes) * N * 8)
+        _lib.call("fb_leading_eigenvectors", eng._plan, cov_dev.ptr, nmodes, U_dev.ptr, None, None, eng.stream)
+    else:
+        cov = np.empty((N, N))
+        _lib.call("fb_memcpy_d2h", cov.ctypes.data_as(ctypes.c_void_p), cov_dev.ptr, cov.nbytes, eng.stream)
+        with _few_blas_threads():
+            if 0 < nmodes < N:
+                from scipy.linalg import eigh      # only the nmodes largest eigenpairs (LAPACK dsyevr)
+                w, v = eigh(cov, subset_by_index=[N - nmodes, N - 1])
+            else:
+                w, v = np.linalg.eigh(cov)
+        U_fg = np.ascontiguousarray(v[:, ::-1][:, :nmodes])
+        U_dev = eng.upload_raw(U_fg)
     out = eng.empty(REAL)
     amps_dev = eng._alloc_bytes(max(1, nmodes) * N * N * 8) if return_filter else None
     _lib.call("fb_pca_clean", eng._plan, cube.ptr, mean.ptr, U_dev.ptr, int(nmodes), out.ptr,
@@ -97,7 +111,12 @@ def pca_filter(field, nmodes, fit_powerlaw=False, return_filter=False, box=None)
     if not return_filter:
         return out
     fg_amps = np.empty((nmodes, N * N))
-    _lib.call("fb_memcpy_d2h", fg_amps.ctypes.data_as(ctypes.c_void_p), amps_dev.ptr, fg_amps.nbytes, eng.stream)
+    if nmodes:
+        _lib.call("fb_memcpy_d2h", fg_amps.ctypes.data_as(ctypes.c_void_p), amps_dev.ptr, fg_amps.nbytes, eng.stream)
+    if U_fg is None:
+        U_fg = np.empty((N, nmodes))
+        if nmodes:
+            _lib.call("fb_memcpy_d2h", U_fg.ctypes.data_as(ctypes.c_void_p), U_dev.ptr, U_fg.nbytes, eng.stream)
     return out, U_fg, fg_amps
 
 

@@ -265,9 +265,17 @@ int fb_beam_convolve(fb_plan* plan, const void* field, const void* beam, void* w
  * mean_dev[N]: per-channel mean over the N^2 pixels (:142), fp64 on the DEVICE.                                   */
 int fb_channel_means(fb_plan* plan, const void* cube, double* mean_dev, void* stream);
 /* cov_dev[N][N] = np.cov of the mean-subtracted channels (:157-158; divisor N^2 - 1), fp64 on the DEVICE, formed on
- * the fp64 matrix cores (v_mfma_f64_16x16x4_f64) with a fixed summation order.  The caller takes its leading
- * eigenvectors (:161-169; an N x N problem) and hands them back as modes_dev[N][nmodes] (fp64, DEVICE).            */
+ * the fp64 matrix cores (v_mfma_f64_16x16x4_f64) with a fixed summation order.  Its leading eigenvectors
+ * (:161-169; an N x N problem): fb_leading_eigenvectors below, or the caller's own solver -- modes_dev[N][nmodes].   */
 int fb_channel_covariance(fb_plan* plan, const void* cube, const double* mean_dev, double* cov_dev, void* stream);
+/* The nmodes leading eigenpairs of cov_dev[N][N] (symmetric, fp64, DEVICE; not modified) -- np.linalg.eig + the sort by
+ * decreasing eigenvalue of :161-169 -- by cyclic two-sided Jacobi in fp64 on the device (round-robin ordering, N/2
+ * rotations per launch; 6-10 sweeps): modes_dev[N][nmodes] (orthonormal columns, the sign of a column is not defined,
+ * as with LAPACK), vals_dev[nmodes] (descending; may be NULL), *sweeps_out (host; may be NULL).  Equal eigenvalues keep
+ * the order of their diagonal positions.  Synchronises the stream (one convergence check per sweep).  FB_ERR_INVALID
+ * for a matrix with non-finite entries, FB_ERR_STATE if 60 sweeps do not converge.  0 <= nmodes <= N.                 */
+int fb_leading_eigenvectors(fb_plan* plan, const double* cov_dev, int nmodes, double* modes_dev, double* vals_dev,
+                            int* sweeps_out, void* stream);
 /* cube_out = cube - (U (U^T x) + mean), x = cube - mean (:172-176); amps_dev[nmodes][N^2] = U^T x (:172) or NULL   */
 int fb_pca_clean(fb_plan* plan, const void* cube, const double* mean_dev, const double* modes_dev, int nmodes,
                  void* cube_out, double* amps_dev, void* stream);

@@ -103,9 +103,11 @@ def test_cube_arithmetic_stays_on_the_device(precision, tol):
 
 @pytest.mark.parametrize("name", ["pca_n16", "pca_n32"])
 @pytest.mark.parametrize("precision,tol", [("f64", 1e-9), ("f32", 3e-6)])
-def test_pca_filter_matches_reference_vectors(golden_dir, name, precision, tol):
+@pytest.mark.parametrize("eigensolver", ["host", "device"])
+def test_pca_filter_matches_reference_vectors(golden_dir, name, precision, tol, eigensolver):
     """fastbox_amd.filters against vectors from the reference's filters.py: the cleaned cube (which depends only on
-    the span of the modes), the projector U U^T, the amplitudes up to a sign per mode."""
+    the span of the modes), the projector U U^T, the amplitudes up to a sign per mode -- with the modes from LAPACK on the host and from
+    fb_leading_eigenvectors on the device."""
     from fastbox_amd import CosmoBox, filters
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     N, data = int(g["N"]), g["data"]
@@ -115,7 +117,7 @@ def test_pca_filter_matches_reference_vectors(golden_dir, name, precision, tol):
     ms = np.asarray(filters.mean_spectrum_filter(cube))
     assert np.max(np.abs(ms - g["mean_sub"])) < tol * scale
     for nm in (2, 4):
-        cleaned, U, amps = filters.pca_filter(cube, nm, return_filter=True)
+        cleaned, U, amps = filters.pca_filter(cube, nm, return_filter=True, eigensolver=eigensolver)
         assert np.max(np.abs(np.asarray(cleaned) - g["cleaned%d" % nm])) < tol * scale
         Ur = g["U%d" % nm].real
         # fp32 storage of the cube perturbs the noise-dominated modes (nearly degenerate eigenvalues) at the 1e-4
@@ -124,11 +126,11 @@ def test_pca_filter_matches_reference_vectors(golden_dir, name, precision, tol):
         sgn = np.sign(np.sum(U * Ur, axis=0))
         ref_amps = g["amps%d" % nm].real
         assert np.max(np.abs(amps * sgn[:, None] - ref_amps)) < (2e-3 if precision == "f32" else 1e-9) * np.max(np.abs(ref_amps))
-        only = filters.pca_filter(data, nm, box=box)                       # host array in, no filter returned
+        only = filters.pca_filter(data, nm, box=box, eigensolver=eigensolver)                       # host array in, no filter returned
         assert np.max(np.abs(np.asarray(only) - g["cleaned%d" % nm])) < tol * scale
         # fit_powerlaw=True: the modes come from the covariance about the TRUE channel means (np.cov re-centres),
         # only the subtracted / restored spectrum is the power-law fit (filters.py:146-158)
-        cleaned, U, amps = filters.pca_filter(cube, nm, fit_powerlaw=True, return_filter=True)
+        cleaned, U, amps = filters.pca_filter(cube, nm, fit_powerlaw=True, return_filter=True, eigensolver=eigensolver)
         # (fp32 storage of the cube moves the channel means by 1e-7, and the least-squares power-law fit of them -- which
         # stays in the cleaned cube, since it is not the true mean spectrum -- answers with 5e-5)
         assert np.max(np.abs(np.asarray(cleaned) - g["cleaned_pl%d" % nm])) < (tol if precision == "f64" else 2e-4) * scale
