@@ -1418,7 +1418,9 @@ static __global__ void k_channel_means(const double* __restrict__ partial, int n
 // loads are 64-byte runs along the channel axis, shared through L1/L2 by the waves of the same pixel slice).  Only
 // blocks with bi <= bj are launched; partial[slice][a][b] are summed in slice order afterwards (deterministic).
 typedef double fb_d4 __attribute__((ext_vector_type(4)));
-template <typename T, int MA>
+// EDGE: N is not a multiple of the block (grids that are not powers of two): channels past N read channel N - 1, count as 0
+// and are not stored.
+template <typename T, int MA, bool EDGE = false>
 __global__ __launch_bounds__(64) void k_channel_cov(const T* __restrict__ cube, const double* __restrict__ mean,
                                                     double* __restrict__ partial, long long npix, int N, int nbs) {
     // blockIdx.x -> (bi <= bj) pair, blockIdx.y -> pixel slice
@@ -1430,8 +1432,15 @@ __global__ __launch_bounds__(64) void k_channel_cov(const T* __restrict__ cube, 
     const long long per = ((npix + gridDim.y - 1) / gridDim.y + 3) & ~3LL;
     const long long p0 = (long long)blockIdx.y * per, p1 = p0 + per < npix ? p0 + per : npix;
     double ma[MA], mb[MA];
+    int ca[MA], cb[MA];                    // channel of this lane in block row i / block column i
+    bool oka[MA], okb[MA];
 #pragma unroll
-    for (int i = 0; i < MA; ++i) { ma[i] = mean[a0 + 16 * i + lc]; mb[i] = mean[b0 + 16 * i + lc]; }
+    for (int i = 0; i < MA; ++i) {
+        ca[i] = a0 + 16 * i + lc; cb[i] = b0 + 16 * i + lc;
+        oka[i] = !EDGE || ca[i] < N; okb[i] = !EDGE || cb[i] < N;
+        if (EDGE) { ca[i] = ca[i] < N ? ca[i] : N - 1; cb[i] = cb[i] < N ? cb[i] : N - 1; }
+        ma[i] = mean[ca[i]]; mb[i] = mean[cb[i]];
+    }
     fb_d4 acc[MA][MA];
 #pragma unroll
     for (int i = 0; i < MA; ++i)
@@ -1447,7 +1456,7 @@ __global__ __launch_bounds__(64) void k_channel_cov(const T* __restrict__ cube, 
             const long long row = p + 4 * u + lk;
             const T* src = cube + (row < p1 ? row : p0) * N;       // past the slice: any valid row, masked below
 #pragma unroll
-            for (int i = 0; i < MA; ++i) { fa[buf][u][i] = src[a0 + 16 * i + lc]; fb_[buf][u][i] = src[b0 + 16 * i + lc]; }
+            for (int i = 0; i < MA; ++i) { fa[buf][u][i] = src[ca[i]]; fb_[buf][u][i] = src[cb[i]]; }
         }
     };
     auto update = [&](int buf, long long p) {
@@ -1457,8 +1466,8 @@ __global__ __launch_bounds__(64) void k_channel_cov(const T* __restrict__ cube, 
             double av[MA], bv[MA];
 #pragma unroll
             for (int i = 0; i < MA; ++i) {
-                av[i] = ok ? (double)fa[buf][u][i] - ma[i] : 0.0;
-                bv[i] = ok ? (double)fb_[buf][u][i] - mb[i] : 0.0;
+                av[i] = (ok && oka[i]) ? (double)fa[buf][u][i] - ma[i] : 0.0;
+                bv[i] = (ok && okb[i]) ? (double)fb_[buf][u][i] - mb[i] : 0.0;
             }
 #pragma unroll
             for (int i = 0; i < MA; ++i)
@@ -1483,7 +1492,8 @@ __global__ __launch_bounds__(64) void k_channel_cov(const T* __restrict__ cube, 
         for (int j = 0; j < MA; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                dst[(size_t)(a0 + 16 * i + lk + 4 * r) * N + b0 + 16 * j + lc] = acc[i][j][r];
+                if (!EDGE || (a0 + 16 * i + lk + 4 * r < N && b0 + 16 * j + lc < N))
+                    dst[(size_t)(a0 + 16 * i + lk + 4 * r) * N + b0 + 16 * j + lc] = acc[i][j][r];
 }
 // cov[a][b] = cov[b][a] = sum over slices / (npix - 1) for a's block <= b's block (np.cov's divisor)
 static __global__ void k_cov_finish(const double* __restrict__ partial, int nslices, int N, int bs, double inv,

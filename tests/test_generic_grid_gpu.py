@@ -128,3 +128,56 @@ def test_device_generator_on_a_grid_that_is_not_a_power_of_two(N):
     okc, opk, oerr = bo.binned_power_spectrum(geo, np.fft.fftn(want))
     m = ~np.isnan(opk)
     assert np.array_equal(kc, okc) and np.allclose(pk[m], opk[m], rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-10), ("f32", 5e-6)])
+@pytest.mark.parametrize("N", [18, 48, 80, 96])
+def test_foreground_cleaning_on_a_grid_that_is_not_a_power_of_two(N, precision, tol):
+    """filters.py:35-56, :93-183 on such a grid: channel means, the covariance on the matrix cores in 16- / 32-channel blocks
+    (masked last block at N = 18, 80 = 5 x 16, 48 = 3 x 16, 96 = 3 x 32), both eigensolvers, the projection -- against
+    the numpy restatement on the cube as the device holds it."""
+    import ctypes
+    from fastbox_amd import CosmoBox, default_cosmo, filters, _lib
+    from oracle import pca_oracle as po
+    box = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False, precision=precision)
+    eng = box.engine
+    rs = np.random.RandomState(N)
+    nu = np.linspace(1., 2., N)
+    data = (40. * nu ** -2.7) * (1. + 0.2 * rs.normal(size=(N, N, 1))) + (3. * nu ** -2.0) * rs.normal(size=(N, N, 1)) \
+        + 0.02 * rs.normal(size=(N, N, N))
+    cube = eng.upload(data, "real")
+    held = np.asarray(cube).astype(np.float64)
+    scale = np.max(np.abs(held))
+    assert np.max(np.abs(np.asarray(filters.mean_spectrum_filter(cube)) - po.mean_spectrum_filter(held))) < tol * scale
+    mean = filters._channel_means(eng, cube)
+    cov_dev = eng._alloc_bytes(N * N * 8)
+    _lib.call("fb_channel_covariance", eng._plan, cube.ptr, mean.ptr, cov_dev.ptr, eng.stream)
+    cov = np.empty((N, N))
+    _lib.call("fb_memcpy_d2h", cov.ctypes.data_as(ctypes.c_void_p), cov_dev.ptr, cov.nbytes, eng.stream)
+    want = np.cov(held.reshape(-1, N).T)
+    assert np.max(np.abs(cov - want)) < 1e-11 * np.max(np.abs(want)) and np.array_equal(cov, cov.T)
+    for solver in ("host", "device"):
+        for nm in (2, 3):
+            got, U, amps = filters.pca_filter(cube, nm, return_filter=True, eigensolver=solver)
+            ref, Ur, ampr = po.pca_filter(held, nm, return_filter=True)
+            assert np.max(np.abs(np.asarray(got) - ref)) < tol * scale
+            Ur = np.real(Ur)
+            assert np.max(np.abs(U @ U.T - Ur @ Ur.T)) < 1e-6
+
+
+def test_what_a_plan_of_such_a_grid_refuses_it_refuses_loudly():
+    """The entry points that fuse work into a power-of-two FFT pass, and the transverse 2-D transforms of the beam / band-pass
+    step, exist for powers of two only: FB_ERR_UNSUPPORTED, never a wrong answer."""
+    from fastbox_amd import CosmoBox, default_cosmo, filters
+    from fastbox_amd._lib import FastBoxError
+    N = 48
+    box = CosmoBox(cosmo=default_cosmo, box_scale=1e3, nsamp=N, realise_now=False, precision="f32")
+    x = np.random.RandomState(0).normal(size=(N, N, N))
+    try:
+        got = np.asarray(filters.angular_bandpass_filter(x, 0.05, 0.3, d=1., box=box))
+    except FastBoxError as e:
+        assert "unsupported" in str(e).lower() or "grid size" in str(e).lower()
+    else:                                   # if it runs, it is right
+        from oracle import pca_oracle as po
+        want = po.angular_bandpass_filter(x.astype(np.float32).astype(np.float64), 0.05, 0.3, d=1.)
+        assert np.max(np.abs(got - want)) < 5e-6 * np.max(np.abs(want))
