@@ -52,8 +52,9 @@ const char* fb_last_error(void);
  * (box.py:119-127, 254-256, 375, 79-88) so that |k| is bit-identical.            */
 /* N: a power of two in 16 .. 2048 (the tuned kernels, every entry point), or any other EVEN size with prime factors 2, 3, 5 in
  * 16 .. 1024 (round 4): there fb_fft_c2c / _r2c / _c2r run plain Stockham passes (radices 4, 2, 3, 5) and every kernel that is not
- * an FFT pass works as usual, while the entry points that fuse something into an FFT pass (fb_realise_density_*,
- * fb_power_spectrum_*, fb_slab_*, fb_fft_transverse, fb_beam_convolve, fb_sky_realise_map) return FB_ERR_UNSUPPORTED: compose
+ * an FFT pass works as usual (the transverse and 2-D transforms behind fb_fft_transverse, fb_beam_convolve, fb_sky_realise_map take
+ * the same plain passes), while the entry points that fuse something into an FFT pass (fb_realise_density_*,
+ * fb_power_spectrum_*, fb_slab_*) return FB_ERR_UNSUPPORTED: compose
  * fb_colour_device / fb_colour_noise + fb_fft_c2r, fb_fft_r2c + fb_bin_power, fb_lognormal ... instead, as
  * fastbox_amd.CosmoBox does on such a grid.  Anything else (odd, other prime factors): FB_ERR_UNSUPPORTED. */
 int fb_plan_create(fb_plan** plan, int N, double Lx, double Ly, double Lz, int precision, int device,

@@ -9,6 +9,8 @@ tests/golden/sky_*.npz (tests/test_oracle.py).
 import numpy as np
 import scipy.ndimage
 
+from .box_oracle import mode_numbers
+
 
 def radiometer_sigma(freqs, ang_x, Tinst, tp, fov, Ndish):
     """noise.py:53-69: rms per frequency channel in mK (freqs in MHz, ang_x in degrees, tp in hours)."""
@@ -31,7 +33,7 @@ def radiometer_noise(shape, sigma_rms, rng=np.random):
 def foreground_cell(g, r, amp, beta):
     """foregrounds.py:83-97: C_ell on the 2-D (k_x, k_y) grid, ell ~ k_perp r / 2, normalised for the 2-D DFT."""
     N = g['N']
-    m = (N * np.fft.fftfreq(N, 1.)).astype('i').astype(np.float64)
+    m = mode_numbers(N)          # the numbering of box.Kx, Ky (box.py:116-123; fftfreq's for a power of two)
     # the reference slices its (N,N,N) mode cubes, Kx[:,:,0]: numpy's vectorised pow/sqrt round some elements
     # differently for strided and contiguous operands, so the operand layout is part of the restatement
     Kx = np.empty((N, N, N)); Ky = np.empty((N, N, N))
