@@ -389,7 +389,8 @@ int fb_comm_info(const fb_plan* plan, int* world, int* rank, int* rccl_version);
 int fb_slab_exchange_begin(fb_plan* plan, const void* send, void* recv, int64_t bytes_per_peer, void* stream, int* ticket);
 int fb_slab_exchange_wait(fb_plan* plan, int ticket, void* stream);   /* `stream` waits for that exchange           */
 int fb_slab_exchange(fb_plan* plan, const void* send, void* recv, int64_t bytes_per_peer, void* stream);   /* begin + wait */
-/* in place on the device, in stream order; op 0 = sum, 1 = max */
+/* in place on the device, in stream order of `stream` (issued, like the exchanges, to the communicator's own stream between two
+ * event hand-overs: every operation of a communicator goes to one stream, in the same order on every rank); op 0 = sum, 1 = max */
 int fb_allreduce_f64(fb_plan* plan, double* data_dev, int count, int op, void* stream);
 
 /* The y and z passes of a transform run x-plane batch by x-plane batch so that a batch stays in the 256 MiB Infinity
