@@ -228,7 +228,8 @@ int fb_crop_full(fb_plan* plan, const void* full, void* half, void* stream);    
 #define FB_PROF_LAYOUT 8
 #define FB_PROF_FFT_GEN 9       /* x pass with the fused Gaussian generator */
 #define FB_PROF_FFT_BIN 10      /* x pass with the fused shell binning      */
-#define FB_PROF_NCAT 11
+#define FB_PROF_PCA 11          /* channel covariance and projection of the PCA cleaning */
+#define FB_PROF_NCAT 12
 /* between start and stop every kernel launch of this plan is bracketed by an event pair;
  * stop synchronises and returns summed milliseconds and launch counts per class above.  */
 int fb_profile_select(fb_plan* plan, unsigned mask);   /* bit i = bracket class i; default all */
