@@ -27,7 +27,7 @@ Prints ONE JSON line (see README / DESIGN.md for the fields).  Besides the contr
   config3            BASELINE configs[2]: gen -> v_z -> redshift space -> wedge filter -> P(k) + filtered field, independent
                      chains on --streams boxes as the headline's realisations (+ one_box, + the remap kernel's own roofline)
   roofline_gen/_bin/_z  the fused generator, binning and z passes, un-overlapped (HIP events on one stream)
-  sizes              N = 1: the same step at 256^3, 1024^3, 2048^3 on this GPU
+  sizes              N = 1: the same step at 128^3 (BASELINE configs[0]), 256^3, 1024^3, 2048^3 on this GPU
   strong_scaling     N > 1: ONE box over all ranks (slab-decomposed FFT, RCCL all-to-all) at 1024^3 and 2048^3,
                      run as child jobs of rank 0 after the replicas leg (a failure there cannot take the line down)
   cpu_baseline       the numpy oracle (the reference's algorithm) on one host core; threaded_fft_variant: the same with scipy.fft on all cores
@@ -72,7 +72,8 @@ def parse(argv=None):
                          "the library's own RCCL communicator behind the C ABI (fb_comm_create / fb_slab_exchange_begin)")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent realisations are issued round-robin on this many HIP streams (boxes)")
-    ap.add_argument("--sizes", default="256,1024,2048", help="N = 1: other grid sizes of the `sizes` leg")
+    ap.add_argument("--sizes", default="128,256,1024,2048",
+                    help="N = 1: other grid sizes of the `sizes` leg (128^3 = BASELINE configs[0], the reference's own CPU-runnable case)")
     ap.add_argument("--slab-sizes", default="1024,2048", help="N > 1: grid sizes of the `strong_scaling` leg")
     ap.add_argument("--spin-up", type=float, default=0.15,
                     help="seconds of untimed steps of the same workload run directly before the warm-up steps: the GPU "
