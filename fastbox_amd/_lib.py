@@ -65,6 +65,7 @@ SIGNATURES = {
     "fb_power_spectrum_redshift_space": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double,
                                                  c_u64, c_int, c_int, P_double, c_void_p, c_int, c_void_p, c_void_p]),
     "fb_power_spectrum_pending": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "fb_montecarlo_power": (c_int, [c_void_p, c_u64, c_u64, c_u64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_void_p]),
     "fb_power_spectrum_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fb_bin_counts": (c_int, [c_void_p, P_double]),
     "fb_real_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_void_p]),

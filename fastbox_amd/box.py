@@ -98,7 +98,7 @@ class PendingSpectrum(object):
                 if lnv:
                     good = hostgeom.lognormal_sums_in_range_many(cnt, s1, s2, esum)
                     mean = esum / lnv
-                    s1, s2 = s1 / (mean ** 2)[:, None], s2 / (mean ** 4)[:, None]
+                    s1, s2 = hostgeom.lognormal_rescale(s1, s2, mean)
                 vals, std = hostgeom.finish_bins_many(cnt, s1, s2, bf, eps)
             for i, o in enumerate(grp):
                 if good[i]:
@@ -121,7 +121,7 @@ class PendingSpectrum(object):
                         raise FloatingPointError("log-normal P(k): non-finite bin sums (sum of exponentials %r); "
                                                  "is the field finite?" % (esum,))
                 mean = esum / self._lnv
-                s1, s2 = s1 / mean ** 2, s2 / mean ** 4
+                s1, s2 = hostgeom.lognormal_rescale(s1, s2, mean)
             self._out = (self._kc,) + _finish_bins(self._cnt, s1, s2, self._bf, _eps_of(self._eng))
             self._res = self._keep = self._redo = None
         return self._out
@@ -509,6 +509,66 @@ class CosmoBox(object):
             self.delta_x = delta_x
             self._delta_k = None          # = fftn(delta_x), materialised on demand
         return delta_x
+
+    def realisation_spectra(self, count, nbins=20, kbins=None, lognormal=False, linear=False, redshift=None, stride=1):
+        """Additive (a Monte-Carlo loop in one call): P(k) of the next `count` realisations of this box's device generator
+        -- indices r, r + stride, ... from the box's counter -- as ``(kc, pk[count, nbins-1], stddev[count, nbins-1])``.
+        The same numbers, realisation by realisation, as
+
+            dx = box.realise_density(); box.binned_power_spectrum(delta_x=box.lognormal(dx) if lognormal else dx, nbins=nbins)
+
+        (box.py:130-194, :441-460, :696-768), but queued by the library itself (fb_montecarlo_power), which is what a
+        small box's step is bound by; the fields are not kept (``box.delta_x`` is left as it was).  Cubic boxes on a
+        power-of-two grid with rng='device'; anything else runs the loop above."""
+        count, stride = int(count), int(stride)
+        if count < 0 or stride < 1:
+            raise ValueError("count >= 0 and stride >= 1")
+        if redshift is None:
+            redshift = self.redshift
+        bins, kc, thr, amb = self._bin_setup(nbins, kbins)
+        first = self._realisation
+        fast = self.rng == "device" and not self._plain and thr is not None and (not lognormal or bins[0] > 0.)
+
+        def one_by_one(indices):
+            rows = []
+            for r in indices:
+                self._realisation = r
+                dx = self.realise_density(linear=linear, redshift=redshift, inplace=False)
+                rows.append(self.binned_power_spectrum(delta_x=self.lognormal(dx) if lognormal else dx, nbins=nbins, kbins=kbins,
+                                                       keep_field=False))
+            return rows
+        if not fast:
+            if self.rng != "device":
+                raise ValueError("realisation_spectra needs rng='device' (realisations addressed by index)")
+            rows = one_by_one([first + i * stride for i in range(count)])
+            self._realisation = first + count * stride
+            return kc.copy(), np.array([r[1] for r in rows]).reshape(count, -1), np.array([r[2] for r in rows]).reshape(count, -1)
+        self._set_amplitude(1. / (1. + redshift), linear)
+        eng = self.engine
+        eng.set_bins(bins, thr, amb)
+        nb = bins.size
+        nvox = float(self.N) ** 3
+        shift = hostgeom.lognormal_shift(self._sigma2, nvox) if lognormal else 0.0
+        R = eng.montecarlo_power(self.seed, first, count, stride=stride, pre_exp=lognormal, exp_shift=shift)
+        self._realisation = first + count * stride
+        self.last_realisation = self._realisation - stride if count else getattr(self, "last_realisation", None)
+        s1, s2, esum = R[:, 0:2 * nb:2], R[:, 1:2 * nb:2], R[:, 2 * nb]
+        cnt = eng.bin_counts()
+        good = np.ones(count, dtype=bool)
+        with np.errstate(all="ignore"):
+            if lognormal:
+                good = hostgeom.lognormal_sums_in_range_many(cnt, s1, s2, esum)
+                mean = esum / nvox
+                s1, s2 = hostgeom.lognormal_rescale(s1, s2, mean)
+            vals, std = hostgeom.finish_bins_many(cnt, s1, s2, self.boxfactor, _eps_of(eng))
+        for i in np.nonzero(~good)[0]:
+            # a realisation whose extremes fall outside what the variance-based shift allows for: once more on its own, where
+            # the step is repeated with the shift from its maximum (binned_power_spectrum)
+            keep = self._realisation
+            row = one_by_one([first + int(i) * stride])[0]
+            self._realisation = keep
+            vals[i], std[i] = row[1], row[2]
+        return kc.copy(), vals, std
 
     # ----------------------------------------------------------- velocity / potential
     def _field_k(self, delta_x, delta_k):

@@ -449,6 +449,28 @@ int fb_power_spectrum_pending(fb_plan* p, void* pending_half, void* real_out, in
     return FB_DISPATCH(p, fbi_power_from_pending_f32(p, pending_half, real_out, scale, pre_exp, results_dev, s),
                        fbi_power_from_pending_f64(p, pending_half, real_out, scale, pre_exp, results_dev, s));
 }
+// The Monte-Carlo loop "draw realisation r, estimate its P(k)" for count realisations in ONE call: per realisation the launches
+// of fb_realise_density_begin + fb_power_spectrum_pending, queued back to back on `stream` (the host's share of a step of a
+// small box -- two library calls from an interpreter -- is the step's limit below 256^3).
+int fb_montecarlo_power(fb_plan* p, uint64_t seed, uint64_t first, uint64_t stride, int count, void* work_half, void* real_out,
+                        int pre_exp, double* results_dev, int64_t results_stride, void* stream) {
+    FB_REQUIRE(p && work_half && results_dev, "null pointer");          // real_out may be NULL: the fields are not written
+    FB_REQUIRE(count >= 0 && stride >= 1, "count >= 0, stride >= 1");
+    FB_USE_DEVICE(p);
+    FB_REQUIRE(results_stride >= 2 * (int64_t)p->nbins + 1, "results_stride: at least 2 nbins + 1 doubles per realisation");
+    hipStream_t s = (hipStream_t)stream;
+    const double scale = 1.0 / ((double)p->N * p->N * p->N);
+    for (int i = 0; i < count; ++i) {
+        const uint64_t real = first + (uint64_t)i * stride;
+        int r = FB_DISPATCH(p, fbi_realise_begin_f32(p, seed, real, work_half, s), fbi_realise_begin_f64(p, seed, real, work_half, s));
+        if (r) return r;
+        double* res = results_dev + (size_t)i * results_stride;
+        r = FB_DISPATCH(p, fbi_power_from_pending_f32(p, work_half, real_out, scale, pre_exp, res, s),
+                        fbi_power_from_pending_f64(p, work_half, real_out, scale, pre_exp, res, s));
+        if (r) return r;
+    }
+    return FB_OK;
+}
 int fb_power_spectrum_device(fb_plan* p, const void* real_in, void* work_half, int pre_exp, int keep_spectrum,
                              double* results_dev, void* stream) {
     FB_REQUIRE(p && real_in && work_half && results_dev, "null pointer");

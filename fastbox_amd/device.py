@@ -570,6 +570,22 @@ class Engine(object):
                   1 if pre_exp else 0, res.ptr, self.stream)
         return res, out
 
+    def montecarlo_power(self, seed, first, count, stride=1, pre_exp=False, exp_shift=0.0):
+        """`count` realisations (seed, first + i stride) drawn and estimated by ONE library call (fb_montecarlo_power: the
+        launches of realise_begin + power_pending(keep_field=False) per realisation, back to back).  Returns the host
+        array [count][2 nbins + 1] of their bin sums (waits for the stream)."""
+        self._set_exp_shift(exp_shift if pre_exp else getattr(self, "_exp_shift", 0.0))
+        nb = self._nbins
+        width = 2 * nb + 1
+        out = np.empty((int(count), width))
+        if count:
+            res = self._alloc_bytes(int(count) * width * 8)
+            work = self._scratch_half()
+            _lib.call("fb_montecarlo_power", self._plan, int(seed) & (2 ** 64 - 1), int(first) & (2 ** 64 - 1), int(stride),
+                      int(count), work.ptr, None, 1 if pre_exp else 0, res.ptr, width, self.stream)
+            _lib.call("fb_memcpy_d2h", _ptr(out), res.ptr, out.nbytes, self.stream)
+        return out
+
     def power_fused(self, real, pre_exp=False, keep_spectrum=False, exp_shift=0.0):
         """Asynchronous r2c + shell binning (cubic boxes).  Returns (results buffer, spectrum or None);
         results = [2*nbins+1] doubles on the device, fetched with `fetch_results`."""

@@ -572,7 +572,7 @@ class SlabBox(object):
             h = redo()
         if lognormal:
             mean = esum / float(self.N) ** 3
-            s1, s2 = s1 / mean ** 2, s2 / mean ** 4
+            s1, s2 = hostgeom.lognormal_rescale(s1, s2, mean)
         return (kc,) + hostgeom.finish_bins(cnt, s1, s2, self.boxfactor, self._eps)
 
     def binned_power_spectrum(self, delta_x=None, nbins=20, kbins=None, lognormal=False):

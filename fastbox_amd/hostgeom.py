@@ -150,6 +150,19 @@ def lognormal_sums_in_range_many(cnt, s1, s2, esum):
         return fin & np.all((a > 0.) | zero, axis=1) & np.all(b * c[ok] >= a * a * (1. - 1e-3), axis=1)
 
 
+def lognormal_rescale(s1, s2, mean):
+    """Bin sums of the transform of exp(d - shift), brought to those of exp(d)/<exp(d)> - 1: s1 / mean^2, s2 / mean^4, with
+    mean = sum(exp(d - shift)) / voxels (scalar, or one per record for (records, nbins) sums).  The powers are formed by
+    multiplications -- exactly rounded on every platform, for a Python float as for a numpy array, which `mean ** 4` is
+    not (numpy's vectorised pow and libm's differ in the last bit on some hosts): one record finished alone and the same
+    record finished in a batch give the same numbers."""
+    m2 = mean * mean
+    m4 = m2 * m2
+    if np.ndim(mean):
+        m2, m4 = m2[:, None], m4[:, None]
+    return s1 / m2, s2 / m4
+
+
 def finish_bins_many(cnt, s1, s2, boxfactor, eps=0.):
     """`finish_bins` for many records at once (s1, s2: (records, nbins)); the same expressions, element for element."""
     with np.errstate(all="ignore"):

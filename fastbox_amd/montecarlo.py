@@ -109,15 +109,22 @@ def run(box, realisations, nbins=20, lognormal=False, batch=50, rank=0, world=1,
     nb = 0
     for start in range(done, len(mine), batch):
         chunk = mine[start:start + batch]
-        pend = []
-        for r in chunk:
-            box._realisation = r                     # the generator's counter: realisation r, whatever ran before
-            dx = box.realise_density()
-            pend.append(box.binned_power_spectrum(delta_x=box.lognormal(dx) if lognormal else dx, nbins=nbins, wait=False,
-                                                  **spectra_only))
-        for p in pend:
-            kc, pk, _ = p.result()
-            acc.add(pk)
+        if not keep_fields and hasattr(box, "realisation_spectra"):
+            # the whole batch queued by one library call (fb_montecarlo_power): the same numbers as the loop below
+            box._realisation = chunk[0]
+            kc, pks, _ = box.realisation_spectra(len(chunk), nbins=nbins, lognormal=lognormal, stride=world)
+            for pk in pks:
+                acc.add(pk)
+        else:
+            pend = []
+            for r in chunk:
+                box._realisation = r                     # the generator's counter: realisation r, whatever ran before
+                dx = box.realise_density()
+                pend.append(box.binned_power_spectrum(delta_x=box.lognormal(dx) if lognormal else dx, nbins=nbins, wait=False,
+                                                      **spectra_only))
+            for p in pend:
+                kc, pk, _ = p.result()
+                acc.add(pk)
         nb += 1
         if checkpoint and (nb % checkpoint_every == 0 or start + batch >= len(mine)):
             _save(checkpoint, dict(ident, done=start + len(chunk)), acc, kc)

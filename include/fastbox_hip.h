@@ -173,6 +173,13 @@ int fb_power_spectrum_device(fb_plan* plan, const void* real_in, void* work_half
  * be regenerated from (seed, realisation) at any time) -- a quarter of the fused z pass's traffic less.            */
 int fb_power_spectrum_pending(fb_plan* plan, void* pending_half, void* real_out, int pre_exp, double* results_dev,
                               void* stream);
+/* A Monte-Carlo loop in one call: for i < count, realisation (seed, first + i stride) is drawn (fb_realise_density_begin into
+ * work_half) and its P(k) estimated (fb_power_spectrum_pending; real_out, if given, receives every field in turn and holds
+ * the last one), results_dev[i * results_stride ...] = the 2 nbins + 1 sums of realisation i.  The same launches in the same
+ * order as the two calls per realisation -- identical numbers -- without an interpreter between them: what a step of a box
+ * below 256^3 is bound by.  Needs the amplitude table and fb_set_bins with thr, like the calls it stands for.               */
+int fb_montecarlo_power(fb_plan* plan, uint64_t seed, uint64_t first, uint64_t stride, int count, void* work_half, void* real_out,
+                        int pre_exp, double* results_dev, int64_t results_stride, void* stream);
 /* number of full-grid modes per bin for the current bin set (host array, nbins doubles) */
 int fb_bin_counts(fb_plan* plan, double* count);
 
